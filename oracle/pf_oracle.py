@@ -1,0 +1,363 @@
+"""CPU oracle for the buffered particle-filter score path (TEST INFRASTRUCTURE ONLY).
+
+This file is a NumPy fp64 *restatement* of the reference algorithm
+(`sgmcmc_ssm/particle_filters/*` + `sgmcmc_ssm/models/{svm,garch,lgssm}`), written
+from the reference's behaviour, not copied from it.  It exists so that the HIP
+path can be checked on a GPU box where the reference is absent.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product package never does: it fails
+loudly when the HIP extension is missing.
+
+Pinning: ``tests/golden/make_golden.py`` runs the *reference itself* (imported
+from ``/root/reference`` in the build container) and stores inputs/outputs in
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this oracle
+against those fixtures with absolute error 0.0.
+
+Reference map (file:line under /root/reference/sgmcmc_ssm):
+  log_normalize            particle_filters/pf.py:374-377
+  multinomial resampling   particle_filters/pf.py:26-30  (RandomState.choice semantics)
+  pf step                  particle_filters/pf.py:7-38
+  nemeth / poyiadjis_N     particle_filters/pf.py:138-181, buffered_smoother.py:175-180
+  pf_filter                particle_filters/pf.py:40-82
+  T-loop                   particle_filters/buffered_smoother.py:12-149
+  average_statistic        particle_filters/buffered_smoother.py:151-154
+  x0                       particle_filters/kernels.py:83-100, models/garch/kernels.py:7-18
+  SVM kernel / score       models/svm/kernels.py:15-64, models/svm/helper.py:342-348
+  GARCH kernels / score    models/garch/kernels.py:49-180, models/garch/helper.py:335-372
+  LGSSM kernels / score    models/lgssm/kernels.py:11-122, models/lgssm/helper.py:1270-1277
+  sufficient statistics    models/lgssm/helper.py:1338-1363, models/garch/helper.py:414-430
+"""
+import numpy as np
+from scipy.special import expit
+
+MODELS = ("svm", "garch", "lgssm")
+# theta layouts (raw parameters, the order of Parameters.var_dict in the reference)
+THETA_NAMES = {
+    "svm": ("A", "LQinv", "LRinv"),                              # svm/parameters.py:21-25
+    "lgssm": ("A", "C", "LQinv", "LRinv"),                       # lgssm/parameters.py:20-25
+    "garch": ("log_mu", "logit_phi", "logit_lambduh", "LRinv"),  # garch/parameters.py:19-22
+}
+# column order of the score statistic (what pf_gradient_estimate unpacks)
+SCORE_NAMES = {
+    "svm": ("LRinv_vec", "LQinv_vec", "A"),                            # svm/helper.py:121-126
+    "lgssm": ("LRinv_vec", "LQinv_vec", "C", "A"),                     # lgssm/helper.py:1136-1142
+    "garch": ("LRinv_vec", "log_mu", "logit_phi", "logit_lambduh"),    # garch/helper.py:109-115
+}
+STATE_DIM = {"svm": 1, "lgssm": 1, "garch": 2}
+DEFAULT_KERNEL = {"svm": "prior", "garch": "optimal", "lgssm": "optimal"}
+LOG_2PI = np.log(2.0 * np.pi)
+
+
+# --------------------------------------------------------------------------
+# derived constants (what the reference's Parameters properties return)
+# --------------------------------------------------------------------------
+def derived(model, theta):
+    """Quantities the kernels/statistics use, computed as the reference's Parameters
+    properties do (variables/covariance.py:128-157, variables/garch_var.py:69-91).
+    Values are kept as 1-element ndarrays of the reference's shapes ((1,1) matrices,
+    (1,) GARCH variables) so every later expression runs through the same NumPy
+    array code paths (e.g. ``arr**-1`` is an exact reciprocal) and rounds identically."""
+    th = dict(zip(THETA_NAMES[model], [float(v) for v in theta]))
+    d = {}
+    mat = lambda v: np.array([[v]], dtype=float)
+    LRinv = mat(th["LRinv"])
+    d["LRinv"] = LRinv
+    d["Rinv"] = LRinv.dot(LRinv.T) + 1e-16 * np.eye(1)
+    d["R"] = d["Rinv"] ** -1
+    if model in ("svm", "lgssm"):
+        d["A"] = mat(th["A"])
+        if model == "lgssm":
+            d["C"] = mat(th["C"])
+        LQinv = mat(th["LQinv"])
+        d["LQinv"] = LQinv
+        d["Qinv"] = LQinv.dot(LQinv.T) + 1e-16 * np.eye(1)
+        d["Q"] = d["Qinv"] ** -1
+    if model == "garch":
+        for k in ("log_mu", "logit_phi", "logit_lambduh"):
+            d[k] = np.atleast_1d(th[k]).astype(float)
+        d["mu"] = np.exp(d["log_mu"])
+        d["phi"] = expit(d["logit_phi"])
+        d["lambduh"] = expit(d["logit_lambduh"])
+        d["alpha"] = d["mu"] * (1 - d["phi"])
+        d["beta"] = d["phi"] * d["lambduh"]
+        d["gamma"] = d["phi"] * (1 - d["lambduh"])
+    return d
+
+
+# --------------------------------------------------------------------------
+# pieces of one PF step
+# --------------------------------------------------------------------------
+def log_normalize(log_weights):
+    """pf.py:374-377"""
+    probs = np.exp(log_weights - np.max(log_weights))
+    probs /= np.sum(probs)
+    return probs
+
+
+def multinomial_ancestors(p, u):
+    """np.random.choice(range(N), size=N, replace=True, p=p) given its N uniforms
+    (pf.py:26-30).  Legacy RandomState.choice: cdf = cumsum(p); cdf /= cdf[-1];
+    searchsorted(cdf, u, side='right')."""
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, u, side="right")
+
+
+def sample_x0(model, prior_mean, prior_var, z0):
+    """kernels.py:83-100 (n=1), garch/kernels.py:7-18.  z0: (N,) standard normals.
+    np.random.normal(loc, scale) is loc + scale*gauss."""
+    N = z0.shape[0]
+    x0 = float(prior_mean) + np.sqrt(float(prior_var)) * z0
+    if model == "garch":
+        x = np.zeros((N, 2))
+        x[:, 0] = x0
+        return x
+    return x0.reshape(N, 1)
+
+
+def kernel_rv(model, kernel, d, x, y, z):
+    """Kernel.rv: x (N,n) parents, y (1,) array, z (N,) normals -> x_next (N,n)."""
+    if model == "svm":
+        if kernel != "prior":
+            raise NotImplementedError("SVM optimal kernel not analytic")  # svm/helper.py:62
+        # svm/kernels.py:34-37
+        return d["LQinv"] ** -1 * z[:, None] + x * d["A"]
+    if model == "lgssm":
+        if kernel == "prior":
+            # lgssm/kernels.py:30-33
+            return d["LQinv"] ** -1 * z[:, None] + x * d["A"]
+        # lgssm/kernels.py:87-97
+        mean_prec = x * d["A"] * d["Qinv"] + y * d["C"] * d["Rinv"]
+        prec = d["Qinv"] + (d["C"] ** 2) * d["Rinv"]
+        return (prec) ** -0.5 * z[:, None] + mean_prec / prec
+    if model == "garch":
+        N = x.shape[0]
+        sigma2_next = d["alpha"] + d["beta"] * x[:, 0] ** 2 + d["gamma"] * x[:, 1]
+        x_next = np.zeros((N, 2))
+        if kernel == "prior":
+            # garch/kernels.py:60-68
+            x_next[:, 0] = np.sqrt(sigma2_next) * z
+        else:
+            # garch/kernels.py:146-156
+            var_next = (d["Rinv"] + sigma2_next ** -1) ** -1
+            mean_next = var_next * (y * d["Rinv"])
+            x_next[:, 0] = mean_next + np.sqrt(var_next) * z
+        x_next[:, 1] = sigma2_next
+        return x_next
+    raise ValueError(model)
+
+
+def kernel_reweight(model, kernel, d, x, x_next, y):
+    """Kernel.reweight -> (N,) log weights."""
+    if model == "svm":
+        # svm/kernels.py:56-62  (diff = y)
+        lw = (-0.5 * LOG_2PI
+              + -0.5 * (y ** 2) * np.exp(-x_next) * d["Rinv"]
+              + np.log(d["LRinv"])
+              + -0.5 * x_next)
+        return lw.reshape(-1)
+    if model == "lgssm":
+        if kernel == "prior":
+            # lgssm/kernels.py:58-62
+            diff = y - d["C"] * x_next
+            lw = (-0.5 * LOG_2PI + -0.5 * (diff ** 2) * d["Rinv"] + np.log(d["LRinv"]))
+        else:
+            # lgssm/kernels.py:117-120 (formula assumes C == 1)
+            diff = y - d["A"] * x
+            variance = d["Qinv"] ** -1 + d["Rinv"] ** -1
+            lw = -0.5 * (diff) ** 2 / variance - 0.5 * LOG_2PI - 0.5 * np.log(variance)
+        return lw.reshape(-1)
+    if model == "garch":
+        if kernel == "prior":
+            # garch/kernels.py:83-88
+            diff = y - x_next[:, 0]
+            lw = (-0.5 * LOG_2PI + -0.5 * (diff ** 2) * d["Rinv"] + np.log(d["LRinv"]))
+        else:
+            # garch/kernels.py:172-178
+            var = x_next[:, 1] + d["R"]
+            lw = (-0.5 * LOG_2PI + -0.5 * (y ** 2) / var + -0.5 * np.log(var))
+        return lw.reshape(-1)
+    raise ValueError(model)
+
+
+def score_statistic(model, d, x, x_next, y):
+    """*_complete_data_loglike_gradient scalar branches -> (N,h)."""
+    if model == "svm":
+        # svm/helper.py:342-348
+        diff_x = x_next - d["A"] * x
+        grad_A = d["Qinv"] * diff_x * x
+        grad_LQinv = (d["LQinv"] ** -1) - (diff_x ** 2) * d["LQinv"]
+        diff_y2 = y ** 2 / np.exp(x_next)
+        grad_LRinv = (d["LRinv"] ** -1) - (diff_y2) * d["LRinv"]
+        return np.hstack([grad_LRinv, grad_LQinv, grad_A])
+    if model == "lgssm":
+        # lgssm/helper.py:1270-1277
+        diff_x = x_next - d["A"] * x
+        grad_A = d["Qinv"] * diff_x * x
+        grad_LQinv = (d["LQinv"] ** -1) - (diff_x ** 2) * d["LQinv"]
+        diff_y = y - d["C"] * x_next
+        grad_C = d["Rinv"] * diff_y * x_next
+        grad_LRinv = (d["LRinv"] ** -1) - (diff_y ** 2) * d["LRinv"]
+        return np.hstack([grad_LRinv, grad_LQinv, grad_C, grad_A])
+    if model == "garch":
+        # garch/helper.py:350-370
+        mu, phi, lam = d["mu"], d["phi"], d["lambduh"]
+        v = x_next[:, 1]
+        grad_v = -0.5 * (v - x_next[:, 0] ** 2) / (v ** 2)
+        grad_log_mu = grad_v * (1 - phi) * mu
+        grad_logit_phi = (grad_v *
+                          (-mu + lam * x[:, 0] ** 2 + (1 - lam) * x[:, 1]) * (1 - phi) * phi)
+        grad_logit_lambduh = (grad_v * phi * (x[:, 0] ** 2 - x[:, 1]) * (1 - lam) * lam)
+        diff_y = y - x_next[:, 0]
+        grad_LRinv = (d["LRinv"] ** -1) - (diff_y ** 2) * d["LRinv"]
+        return np.array([grad_LRinv[0], grad_log_mu, grad_logit_phi, grad_logit_lambduh]).T
+    raise ValueError(model)
+
+
+def sufficient_statistic(model, x, x_next):
+    """gaussian_sufficient_statistics (lgssm/helper.py:1360-1362) /
+    garch_sufficient_statistics (garch/helper.py:429) -> (N,3)."""
+    if model == "garch":
+        return np.array([x_next[:, 0], x_next[:, 0] ** 2, x_next[:, 0] ** 4]).T
+    return np.hstack([x_next, x_next ** 2, x * x_next])
+
+
+STAT_DIM = {
+    ("svm", "score"): 3, ("lgssm", "score"): 4, ("garch", "score"): 4,
+    ("svm", "suff"): 3, ("lgssm", "suff"): 3, ("garch", "suff"): 3,
+}
+
+
+# --------------------------------------------------------------------------
+# RNG stream (order verified against the reference: finding 1 of SURVEY.md)
+# --------------------------------------------------------------------------
+def draw_streams(rng, N, T):
+    """Consume the legacy stream as one PF run of the reference does: N normals (x0),
+    then per timestep N uniforms (np.random.choice) followed by N normals (Kernel.rv).
+    `rng` is `np.random` (global legacy state) or a `np.random.RandomState`."""
+    z0 = rng.normal(size=N)
+    u = np.empty((T, N))
+    z = np.empty((T, N))
+    for t in range(T):
+        u[t] = rng.random_sample(N)
+        z[t] = rng.normal(size=N)
+    return z0, u, z
+
+
+# --------------------------------------------------------------------------
+# the T-loop (buffered_smoother.py:12-149) on pre-drawn streams
+# --------------------------------------------------------------------------
+def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
+              lambduh=None, stat="score", t1=0, tL=None, weights=None,
+              prior_mean=0.0, prior_var=1.0, save_all=False):
+    """One buffered PF window.
+
+    Args:
+      model: 'svm' | 'garch' | 'lgssm';  theta: raw parameters (THETA_NAMES order)
+      y: (T,) or (T,1) observations of the buffered window
+      z0 (N,), u (T,N), z (T,N): the random streams (see draw_streams)
+      pf: 'poyiadjis_N' (lambda=1), 'nemeth' (default lambda .95), 'filter'
+      stat: 'score' | 'suff' | 'none'
+    Returns dict(x_t, log_weights, statistics, loglikelihood_estimate[, mean_statistic, all_*])
+    """
+    y = np.asarray(y, dtype=float).reshape(-1, 1)   # y[t] is a (1,) array as in the reference
+    T = y.shape[0]
+    if tL is None:
+        tL = T
+    if kernel is None:
+        kernel = DEFAULT_KERNEL[model]
+    if pf == "poyiadjis_N":
+        lambduh = 1.0
+    elif pf == "nemeth":
+        lambduh = 0.95 if lambduh is None else lambduh
+    elif pf != "filter":
+        raise ValueError("Unrecognized pf = {0}".format(pf))
+    is_filter = (pf == "filter")
+    d = derived(model, theta)
+    if model == "svm" and abs(d["A"]) > 1:
+        raise ValueError("Current AR parameter is |A| = {0} > 1".format(abs(d["A"])))
+    h = 3 if stat == "none" else STAT_DIM[(model, stat)]
+
+    x = sample_x0(model, prior_mean, prior_var, z0)
+    logw = np.zeros(N)
+    loglik = 0.0
+    stats = np.zeros(h) if is_filter else np.zeros((N, h))
+    if save_all:
+        all_x, all_lw, all_s, all_ll = [x], [logw], [stats], [loglik]
+
+    for t in range(T):
+        inside = (t >= t1) and (t < tL)
+        weight_t = 1.0
+        if inside and weights is not None:
+            weight_t = float(weights[t - t1])
+
+        if not is_filter:
+            # nemeth_smoother: S from the *previous* weights (pf.py:161)
+            S = np.sum(stats.T * log_normalize(logw), axis=1)
+        # pf(): resample every step, propose, weight (pf.py:26-38)
+        anc = multinomial_ancestors(log_normalize(logw), u[t])
+        parents = x[anc]
+        x_next = kernel_rv(model, kernel, d, parents, y[t], z[t])
+        new_logw = kernel_reweight(model, kernel, d, parents, x_next, y[t])
+
+        if inside and stat == "score":
+            add = score_statistic(model, d, parents, x_next, y[t])
+        elif inside and stat == "suff":
+            add = sufficient_statistic(model, parents, x_next)
+        else:
+            add = np.zeros((N, h))      # zero_statistics (buffered_smoother.py:77-79)
+        add = add * weight_t            # additive_scale
+
+        if is_filter:
+            # pf.py:78-80, new weights
+            stats = stats + np.sum(add.T * log_normalize(new_logw), axis=1)
+        else:
+            # pf.py:175-179
+            stats = (lambduh * stats[anc]
+                     + (1.0 - lambduh) * np.outer(np.ones(N), S)
+                     + add)
+        x, logw = x_next, new_logw
+        if inside:
+            # buffered_smoother.py:124-126 (not max-stabilised in the reference)
+            loglik += weight_t * np.log(np.mean(np.exp(logw)))
+        if save_all:
+            all_x.append(x); all_lw.append(logw); all_s.append(stats); all_ll.append(loglik)
+
+    out = dict(x_t=x, log_weights=logw, statistics=stats,
+               loglikelihood_estimate=loglik)
+    if not is_filter:
+        # average_statistic (buffered_smoother.py:151-154)
+        out["mean_statistic"] = np.sum(stats.T * log_normalize(logw), axis=1)
+    if save_all:
+        out["all_x_t"] = np.array(all_x)
+        out["all_log_weights"] = np.array(all_lw)
+        out["all_statistics"] = np.array(all_s)
+        out["all_loglikelihood_estimate"] = np.array(all_ll)
+    return out
+
+
+def pf_window_rng(model, theta, y, N, rng=np.random, **kw):
+    """pf_window drawing its streams from `rng` in the reference's order; the drop-in
+    equivalent of Helper.pf_gradient_estimate's inner buffered_pf_wrapper call."""
+    T = np.asarray(y).reshape(-1).shape[0]
+    z0, u, z = draw_streams(rng, N, T)
+    return pf_window(model, theta, y, N, z0, u, z, **kw)
+
+
+def pf_gradient_estimate(model, theta, y, N, rng=np.random, **kw):
+    """Helper.pf_gradient_estimate -> dict keyed like the reference (SCORE_NAMES)."""
+    out = pf_window_rng(model, theta, y, N, rng=rng, stat="score", **kw)
+    return dict(zip(SCORE_NAMES[model], out["mean_statistic"]))
+
+
+def pf_loglikelihood_estimate(model, theta, y, N, rng=np.random, **kw):
+    """Helper.pf_loglikelihood_estimate."""
+    out = pf_window_rng(model, theta, y, N, rng=rng, stat="suff", **kw)
+    return out["loglikelihood_estimate"]
+
+
+def garch_prior_x(theta):
+    """garch/helper.py:324-332 with forward_message=None."""
+    d = derived("garch", theta)
+    return 0.0, d["alpha"] / (1 - d["beta"] - d["gamma"])

@@ -1,0 +1,378 @@
+"""Generate the golden fixtures by running the REFERENCE itself.
+
+Run only in the build container (the reference lives at /root/reference and never
+travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes tests/golden/{pf_trace,pf_window,host,sampler}.npz.  Fixtures are data only:
+inputs (observations, raw parameters, seeds, window bounds, weights) and the
+reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
+frozen, so tests regenerate them from the seed.
+"""
+import os
+import sys
+import json
+import warnings
+
+warnings.filterwarnings("ignore")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import numpy as np  # noqa: E402
+
+from sgmcmc_ssm.particle_filters.buffered_smoother import (  # noqa: E402
+    buffered_pf_wrapper, average_statistic)
+from sgmcmc_ssm.models.svm import (  # noqa: E402
+    SVMParameters, SVMPrior, SVMHelper, SVMSampler, SeqSVMSampler, generate_svm_data)
+from sgmcmc_ssm.models.svm.kernels import SVMPriorKernel  # noqa: E402
+from sgmcmc_ssm.models.svm.helper import svm_complete_data_loglike_gradient  # noqa: E402
+from sgmcmc_ssm.models.garch import (  # noqa: E402
+    GARCHParameters, GARCHPrior, GARCHHelper, GARCHSampler, SeqGARCHSampler,
+    generate_garch_data)
+from sgmcmc_ssm.models.garch.kernels import GARCHPriorKernel, GARCHOptimalKernel  # noqa: E402
+from sgmcmc_ssm.models.garch.helper import (  # noqa: E402
+    garch_complete_data_loglike_gradient, garch_sufficient_statistics)
+from sgmcmc_ssm.models.lgssm import (  # noqa: E402
+    LGSSMParameters, LGSSMPrior, LGSSMHelper, LGSSMSampler, SeqLGSSMSampler,
+    generate_lgssm_data)
+from sgmcmc_ssm.models.lgssm.kernels import LGSSMPriorKernel, LGSSMOptimalKernel  # noqa: E402
+from sgmcmc_ssm.models.lgssm.helper import (  # noqa: E402
+    lgssm_complete_data_loglike_gradient, gaussian_sufficient_statistics)
+from sgmcmc_ssm.sgmcmc_sampler import random_subsequence_and_weights  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def svm_params(A=0.95, Q=0.5, R=0.5):
+    return SVMParameters(A=np.eye(1) * A, Q=np.eye(1) * Q, R=np.eye(1) * R)
+
+
+def lgssm_params(A=0.9, C=1.0, Q=0.7, R=1.0):
+    return LGSSMParameters(A=np.eye(1) * A, C=np.eye(1) * C, Q=np.eye(1) * Q, R=np.eye(1) * R)
+
+
+def garch_params(alpha=0.1, beta=0.8, gamma=0.05, R=0.3):
+    log_mu, logit_phi, logit_lambduh = GARCHParameters.convert_alpha_beta_gamma(alpha, beta, gamma)
+    return GARCHParameters(log_mu=log_mu, logit_phi=logit_phi, logit_lambduh=logit_lambduh,
+                           LRinv=np.eye(1) * R ** -0.5)
+
+
+def theta_of(model, p):
+    if model == "svm":
+        return np.array([p.A[0, 0], p.LQinv[0, 0], p.LRinv[0, 0]])
+    if model == "lgssm":
+        return np.array([p.A[0, 0], p.C[0, 0], p.LQinv[0, 0], p.LRinv[0, 0]])
+    return np.array([p.log_mu[0], p.logit_phi[0], p.logit_lambduh[0], p.LRinv[0, 0]])
+
+
+MODEL_SETUP = {
+    "svm": dict(params=svm_params, gen=generate_svm_data,
+                kernels=dict(prior=SVMPriorKernel),
+                score=svm_complete_data_loglike_gradient, h=3,
+                suff=gaussian_sufficient_statistics),
+    "lgssm": dict(params=lgssm_params, gen=generate_lgssm_data,
+                  kernels=dict(prior=LGSSMPriorKernel, optimal=LGSSMOptimalKernel),
+                  score=lgssm_complete_data_loglike_gradient, h=4,
+                  suff=gaussian_sufficient_statistics),
+    "garch": dict(params=garch_params, gen=generate_garch_data,
+                  kernels=dict(prior=GARCHPriorKernel, optimal=GARCHOptimalKernel),
+                  score=garch_complete_data_loglike_gradient, h=4,
+                  suff=garch_sufficient_statistics),
+}
+
+
+def prior_x(model, p, data):
+    msg = data["initial_message"]
+    prior_var = np.linalg.inv(msg["precision"])
+    prior_mean = np.linalg.solve(prior_var, msg["mean_precision"])
+    return float(prior_mean[0]), float(prior_var[0, 0])
+
+
+def run_window(model, kernel, pf, stat, p, y, N, t1, tL, weights, pm, pv, seed,
+               save_all=False, lambduh=None):
+    cfg = MODEL_SETUP[model]
+    K = cfg["kernels"][kernel]()
+    func = cfg["score"] if stat == "score" else cfg["suff"]
+    h = cfg["h"] if stat == "score" else 3
+    kw = {}
+    if lambduh is not None:
+        kw["lambduh"] = lambduh
+    np.random.seed(seed)
+    out = buffered_pf_wrapper(
+        pf=pf, observations=y, parameters=p, N=N, kernel=K,
+        additive_statistic_func=func, statistic_dim=h,
+        t1=t1, tL=tL, weights=weights,
+        prior_mean=np.array([pm]), prior_var=np.array([[pv]]) if model != "garch" else pv,
+        save_all=save_all, **kw)
+    if pf != "filter":
+        out["mean_statistic"] = average_statistic(out)
+    return out
+
+
+def make_pf_fixtures():
+    trace, window = {}, {}
+    trace_meta, window_meta = [], []
+    combos = [("svm", "prior"), ("garch", "prior"), ("garch", "optimal"),
+              ("lgssm", "prior"), ("lgssm", "optimal")]
+    # ---- tiny traced cases --------------------------------------------------
+    N, T, t1, tL = 32, 16, 3, 13
+    for ci, (model, kernel) in enumerate(combos):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(100 + ci)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        pm, pv = prior_x(model, p, data)
+        weights = 1.0 + 0.25 * np.arange(tL - t1)
+        for pf, stat, lam in [("poyiadjis_N", "score", None), ("nemeth", "score", None),
+                              ("nemeth", "score", 0.7), ("filter", "score", None),
+                              ("poyiadjis_N", "suff", None)]:
+            seed = 1000 + 10 * ci
+            out = run_window(model, kernel, pf, stat, p, y, N, t1, tL, weights, pm, pv,
+                             seed, save_all=True, lambduh=lam)
+            key = "c{0}".format(len(trace_meta))
+            trace_meta.append(dict(key=key, model=model, kernel=kernel, pf=pf, stat=stat,
+                                   lambduh=lam, N=N, T=T, t1=t1, tL=tL, seed=seed,
+                                   prior_mean=pm, prior_var=pv))
+            trace[key + "/y"] = y.reshape(-1)
+            trace[key + "/theta"] = theta_of(model, p)
+            trace[key + "/weights"] = weights
+            for name in ("all_x_t", "all_log_weights", "all_statistics",
+                         "all_loglikelihood_estimate"):
+                trace[key + "/" + name] = np.asarray(out[name], dtype=float)
+            if pf != "filter":
+                trace[key + "/mean_statistic"] = out["mean_statistic"]
+    # ---- window-level cases (final outputs only) ----------------------------
+    specs = [
+        # model, kernel, pf, T, N, (t1,tL), weights?, data_seed, run_seed
+        ("svm", "prior", "poyiadjis_N", 1000, 1000, None, False, 12345, 99),      # SURVEY 8c known answer
+        ("svm", "prior", "poyiadjis_N", 24, 1000, (4, 20), True, 12345, 7),
+        ("svm", "prior", "nemeth", 24, 1000, (4, 20), True, 12345, 8),
+        ("svm", "prior", "poyiadjis_N", 24, 4000, (4, 20), True, 12345, 9),
+        ("svm", "prior", "poyiadjis_N", 24, 10000, (4, 20), True, 12345, 10),
+        ("garch", "optimal", "poyiadjis_N", 24, 1000, (4, 20), True, 222, 11),
+        ("garch", "prior", "poyiadjis_N", 24, 1000, (4, 20), True, 222, 12),
+        ("garch", "optimal", "poyiadjis_N", 1000, 1000, None, False, 222, 13),
+        ("garch", "optimal", "nemeth", 100, 500, (10, 90), False, 222, 14),
+        ("lgssm", "optimal", "poyiadjis_N", 200, 100, None, False, 333, 15),      # config 1
+        ("lgssm", "prior", "poyiadjis_N", 200, 100, None, False, 333, 16),
+        ("lgssm", "optimal", "nemeth", 32, 1000, (8, 24), False, 333, 17),
+        ("lgssm", "optimal", "filter", 32, 1000, (8, 24), False, 333, 18),
+        ("svm", "prior", "filter", 24, 1000, (4, 20), True, 12345, 19),
+        ("svm", "prior", "poyiadjis_N", 40, 1000, (0, 40), False, 12345, 20),
+        ("svm", "prior", "poyiadjis_N", 17, 999, (0, 16), True, 12345, 21),       # ragged N
+        ("garch", "optimal", "poyiadjis_N", 9, 65, (2, 9), True, 222, 22),         # ragged N, window to the end
+        ("lgssm", "optimal", "poyiadjis_N", 1, 64, (0, 1), False, 333, 23),        # single step
+    ]
+    data_cache = {}
+    for model, kernel, pf, T, N, win, use_w, dseed, seed in specs:
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        if (model, dseed) not in data_cache:
+            np.random.seed(dseed)
+            data_cache[(model, dseed)] = cfg["gen"](T=1000, parameters=p)
+        data = data_cache[(model, dseed)]
+        pm, pv = prior_x(model, p, data)
+        if T == 1000:
+            y = data["observations"]
+        else:
+            y = data["observations"][300:300 + T]
+        t1, tL = (0, T) if win is None else win
+        weights = None
+        if use_w:
+            weights = np.linspace(40.0, 61.0, tL - t1)
+        for stat in ("score", "suff"):
+            if stat == "suff" and pf != "poyiadjis_N":
+                continue
+            out = run_window(model, kernel, pf, stat, p, y, N, t1, tL, weights, pm, pv, seed)
+            key = "w{0}".format(len(window_meta))
+            window_meta.append(dict(key=key, model=model, kernel=kernel, pf=pf, stat=stat,
+                                    lambduh=None, N=N, T=T, t1=t1, tL=tL, seed=seed,
+                                    prior_mean=pm, prior_var=pv, has_weights=bool(use_w)))
+            window[key + "/y"] = y.reshape(-1)
+            window[key + "/theta"] = theta_of(model, p)
+            if use_w:
+                window[key + "/weights"] = weights
+            window[key + "/loglikelihood_estimate"] = np.float64(out["loglikelihood_estimate"])
+            if pf != "filter":
+                window[key + "/mean_statistic"] = out["mean_statistic"]
+            else:
+                window[key + "/statistics"] = out["statistics"]
+            if N <= 1000 and T <= 40:
+                window[key + "/x_t"] = out["x_t"]
+                window[key + "/log_weights"] = out["log_weights"]
+    trace["meta"] = np.array(json.dumps(trace_meta))
+    window["meta"] = np.array(json.dumps(window_meta))
+    np.savez_compressed(os.path.join(HERE, "pf_trace.npz"), **trace)
+    np.savez_compressed(os.path.join(HERE, "pf_window.npz"), **window)
+    # helper-level known answer of SURVEY 8c
+    p = svm_params()
+    data = data_cache[("svm", 12345)]
+    helper = SVMHelper(forward_message=data["initial_message"], **p.dim)
+    np.random.seed(99)
+    g = helper.pf_gradient_estimate(observations=data["observations"], parameters=p, N=1000,
+                                    forward_message=data["initial_message"])
+    print("svm known answer", g)
+
+
+def as_vec(model, d):
+    names = {"svm": ("A", "LQinv_vec", "LRinv_vec"),
+             "lgssm": ("A", "C", "LQinv_vec", "LRinv_vec"),
+             "garch": ("log_mu", "logit_phi", "logit_lambduh", "LRinv_vec")}[model]
+    return np.array([float(np.asarray(d[k]).reshape(-1)[0]) for k in names])
+
+
+def make_host_fixtures():
+    host = {}
+    meta = dict(subseq=[], prior=[], project=[])
+    # random_subsequence_and_weights (sgmcmc_sampler.py:1969-2017)
+    for i, (S, T, seed) in enumerate([(16, 300, 0), (16, 1000, 1), (40, 1000, 2), (16, 20, 3),
+                                      (5, 12, 4), (16, 1000, 5), (16, 1000, 6), (3, 1000, 7),
+                                      (16, 33, 8), (10, 48, 9), (16, 126, 10), (999, 1000, 11)]):
+        for rep in range(3):
+            np.random.seed(seed * 10 + rep)
+            s, e, w = random_subsequence_and_weights(S=S, T=T)
+            key = "subseq{0}_{1}".format(i, rep)
+            meta["subseq"].append(dict(key=key, S=S, T=T, seed=seed * 10 + rep, start=s, end=e))
+            host[key + "/weights"] = w
+    # priors: default prior, grad_logprior / logprior
+    for model, Prior, mk, var in [("svm", SVMPrior, svm_params, 100.0),
+                                  ("lgssm", LGSSMPrior, lgssm_params, 100.0),
+                                  ("garch", GARCHPrior, garch_params, 1.0),
+                                  ("garch", GARCHPrior, garch_params, 100.0),
+                                  ("svm", SVMPrior, svm_params, 1.0)]:
+        prior = Prior.generate_default_prior(var=var, n=1, m=1)
+        for j, scale in enumerate([1.0, 0.7, 1.3]):
+            p = mk()
+            for k in p.var_dict:
+                p.var_dict[k] = p.var_dict[k] * scale
+            g = prior.grad_logprior(p)
+            key = "prior_{0}_{1}_{2}".format(model, var, j)
+            meta["prior"].append(dict(key=key, model=model, var=var))
+            host[key + "/theta"] = theta_of(model, p)
+            host[key + "/grad"] = as_vec(model, g)
+            host[key + "/logprior"] = np.float64(prior.logprior(p))
+    # projection
+    cases = [("svm", SVMParameters, dict(A=np.eye(1) * 1.2, LQinv=np.eye(1) * -0.8, LRinv=np.eye(1) * 1.1)),
+             ("svm", SVMParameters, dict(A=np.eye(1) * -1.7, LQinv=np.eye(1) * 0.8, LRinv=np.eye(1) * -1e-3)),
+             ("svm", SVMParameters, dict(A=np.eye(1) * 0.5, LQinv=np.eye(1) * 0.8, LRinv=np.eye(1) * 1.1)),
+             ("lgssm", LGSSMParameters, dict(A=np.eye(1) * 1.01, C=np.eye(1) * 0.3, LQinv=np.eye(1) * -2.0, LRinv=np.eye(1) * 1.0)),
+             ("garch", GARCHParameters, dict(log_mu=0.3, logit_phi=5.0, logit_lambduh=-7.0, LRinv=np.eye(1) * -0.4))]
+    for i, (model, P, kw) in enumerate(cases):
+        p = P(**kw)
+        before = theta_of(model, p)
+        p.project_parameters()
+        key = "project{0}".format(i)
+        meta["project"].append(dict(key=key, model=model))
+        host[key + "/before"] = before
+        host[key + "/after"] = theta_of(model, p)
+    host["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "host.npz"), **host)
+
+
+def make_sampler_fixtures():
+    """Sampler-level trajectories: noisy_gradient, sample_sgld + project_parameters, fit."""
+    out = {}
+    meta = []
+    setups = [
+        ("svm", SVMSampler, SeqSVMSampler, svm_params, generate_svm_data, 12345, 0.1),
+        ("garch", GARCHSampler, SeqGARCHSampler, garch_params, generate_garch_data, 222, 0.01),
+        ("lgssm", LGSSMSampler, SeqLGSSMSampler, lgssm_params, generate_lgssm_data, 333, 0.1),
+    ]
+    for model, Sampler, SeqSampler, mk, gen, dseed, eps in setups:
+        p0 = mk()
+        np.random.seed(dseed)
+        data = gen(T=200, parameters=p0)
+        y = data["observations"]
+        out[model + "/y"] = y.reshape(-1)
+        out[model + "/theta0"] = theta_of(model, p0)
+        for S, B, N, nsteps in [(-1, -1, 200, 3), (16, 4, 300, 5)]:
+            for pfname in ("poyiadjis_N", "nemeth"):
+                kwargs = dict(kind="pf", pf=pfname, N=N, subsequence_length=S, buffer_length=B,
+                              minibatch_size=1)
+                sampler = Sampler(n=1, m=1, observations=y, parameters=mk())
+                seed = 4242 + (S > 0) * 7 + (pfname == "nemeth")
+                key = "{0}_S{1}_{2}".format(model, S, pfname)
+                # noisy_gradient
+                np.random.seed(seed)
+                g = sampler.noisy_gradient(**kwargs)
+                out[key + "/noisy_gradient"] = as_vec(model, g)
+                np.random.seed(seed)
+                g = sampler.noisy_gradient(is_scaled=False, **kwargs)
+                out[key + "/noisy_gradient_unscaled"] = as_vec(model, g)
+                np.random.seed(seed)
+                ll = sampler.noisy_loglikelihood(**kwargs)
+                out[key + "/noisy_loglikelihood"] = np.float64(ll)
+                # SGLD trajectory
+                np.random.seed(seed + 1)
+                traj = [theta_of(model, sampler.parameters)]
+                for _ in range(nsteps):
+                    sampler.sample_sgld(epsilon=eps, **kwargs)
+                    traj.append(theta_of(model, sampler.parameters))     # before projection
+                    sampler.project_parameters()
+                    traj.append(theta_of(model, sampler.parameters))
+                out[key + "/sgld_traj"] = np.array(traj)
+                # fit(): SGD and ADAGRAD, output_all
+                for it in ("SGD", "ADAGRAD", "SGLD"):
+                    sampler = Sampler(n=1, m=1, observations=y, parameters=mk())
+                    np.random.seed(seed + 2)
+                    plist = sampler.fit(iter_type=it, num_iters=3, output_all=True, epsilon=eps * 0.1,
+                                        subsequence_length=S, buffer_length=B, kind="pf",
+                                        pf_kwargs=dict(pf=pfname, N=N))
+                    out[key + "/fit_" + it] = np.array([theta_of(model, q) for q in plist])
+                meta.append(dict(key=key, model=model, S=S, B=B, N=N, pf=pfname, seed=seed,
+                                 eps=eps, nsteps=nsteps))
+        # minibatch_size = 2
+        sampler = Sampler(n=1, m=1, observations=y, parameters=mk())
+        np.random.seed(77)
+        g = sampler.noisy_gradient(kind="pf", pf="poyiadjis_N", N=100, subsequence_length=10,
+                                   buffer_length=3, minibatch_size=2)
+        out[model + "/minibatch2"] = as_vec(model, g)
+        # Seq sampler on 4 ragged sequences
+        seqs = [y[0:60], y[60:95], y[95:160], y[160:200]]
+        for nseq in (1, -1):
+            sampler = SeqSampler(n=1, m=1, observations=seqs, parameters=mk())
+            np.random.seed(99 + nseq)
+            g = sampler.noisy_gradient(kind="pf", pf="poyiadjis_N", N=150, subsequence_length=16,
+                                       buffer_length=4, num_sequences=nseq)
+            out["{0}/seq_grad_{1}".format(model, nseq)] = as_vec(model, g)
+            np.random.seed(199 + nseq)
+            traj = [theta_of(model, sampler.parameters)]
+            for _ in range(3):
+                sampler.sample_sgld(epsilon=eps * 0.1, kind="pf", pf="poyiadjis_N", N=150,
+                                    subsequence_length=16, buffer_length=4, num_sequences=nseq)
+                sampler.project_parameters()
+                traj.append(theta_of(model, sampler.parameters))
+            out["{0}/seq_traj_{1}".format(model, nseq)] = np.array(traj)
+            np.random.seed(299 + nseq)
+            try:
+                ll = sampler.noisy_loglikelihood(kind="pf", pf="poyiadjis_N", N=150,
+                                                 subsequence_length=16, buffer_length=4,
+                                                 num_sequences=nseq)
+                out["{0}/seq_loglike_{1}".format(model, nseq)] = np.float64(ll)
+            except IndexError:
+                # reference quirk: SeqLGSSMSampler.noisy_loglikelihood re-checks the shape of a
+                # single sequence as if it were a list of sequences and raises (sampler.py:61)
+                print("seq noisy_loglikelihood raises IndexError for", model)
+    # LGSSM: exact Kalman gradient for the PF-bias test (lgssm/helper.py:312-420)
+    p = lgssm_params()
+    np.random.seed(333)
+    data = generate_lgssm_data(T=200, parameters=p)
+    helper = LGSSMHelper(forward_message=data["initial_message"], **p.dim)
+    g = helper.gradient_marginal_loglikelihood(observations=data["observations"], parameters=p,
+                                               forward_message=data["initial_message"])
+    out["lgssm/exact_grad"] = as_vec("lgssm", g)
+    out["lgssm/exact_grad_prior_prec"] = np.float64(data["initial_message"]["precision"][0, 0])
+    ll = helper.marginal_loglikelihood(observations=data["observations"], parameters=p,
+                                       forward_message=data["initial_message"])
+    out["lgssm/exact_loglike"] = np.float64(ll)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_pf_fixtures()
+    make_host_fixtures()
+    make_sampler_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

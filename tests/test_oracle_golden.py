@@ -1,0 +1,96 @@
+"""Pin the CPU oracle: it must reproduce the REFERENCE's outputs (tests/golden, produced
+by tests/golden/make_golden.py from /root/reference) with absolute error 0.0."""
+import numpy as np
+import pytest
+
+from oracle import pf_oracle as po
+
+
+def _run(meta, g, save_all):
+    key = meta["key"]
+    y = g.get(key, "y")
+    theta = g.get(key, "theta")
+    weights = g.get(key, "weights")
+    rng = np.random.RandomState(meta["seed"])
+    z0, u, z = po.draw_streams(rng, meta["N"], meta["T"])
+    return po.pf_window(meta["model"], theta, y, meta["N"], z0, u, z,
+                        kernel=meta["kernel"], pf=meta["pf"], lambduh=meta["lambduh"],
+                        stat=meta["stat"], t1=meta["t1"], tL=meta["tL"], weights=weights,
+                        prior_mean=meta["prior_mean"], prior_var=meta["prior_var"],
+                        save_all=save_all)
+
+
+def test_trace_cases_bit_exact(golden_trace):
+    g = golden_trace
+    assert len(g.meta) == 25
+    for meta in g.meta:
+        out = _run(meta, g, save_all=True)
+        for name in ("all_x_t", "all_log_weights", "all_statistics",
+                     "all_loglikelihood_estimate"):
+            ref = g.get(meta["key"], name)
+            got = np.asarray(out[name], dtype=float)
+            assert got.shape == ref.shape, (meta, name)
+            assert np.array_equal(got, ref), (meta, name, np.max(np.abs(got - ref)))
+        if meta["pf"] != "filter":
+            assert np.array_equal(out["mean_statistic"], g.get(meta["key"], "mean_statistic"))
+
+
+def test_window_cases_bit_exact(golden_window):
+    g = golden_window
+    for meta in g.meta:
+        if meta["N"] * meta["T"] > 300000:
+            continue   # the big ones run in test_window_big (kept separate for timing)
+        out = _run(meta, g, save_all=False)
+        key = meta["key"]
+        assert out["loglikelihood_estimate"] == float(g.get(key, "loglikelihood_estimate")), meta
+        if meta["pf"] != "filter":
+            assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic")), meta
+        else:
+            assert np.array_equal(out["statistics"], g.get(key, "statistics")), meta
+        if g.get(key, "x_t") is not None:
+            assert np.array_equal(out["x_t"], g.get(key, "x_t"))
+            assert np.array_equal(out["log_weights"], g.get(key, "log_weights"))
+
+
+def test_window_big(golden_window):
+    g = golden_window
+    n = 0
+    for meta in g.meta:
+        if meta["N"] * meta["T"] <= 300000 or meta["stat"] != "score":
+            continue
+        out = _run(meta, g, save_all=False)
+        key = meta["key"]
+        assert out["loglikelihood_estimate"] == float(g.get(key, "loglikelihood_estimate")), meta
+        assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic")), meta
+        n += 1
+    assert n >= 2
+
+
+def test_known_answer_svm(golden_window):
+    """SVM A=.95,Q=.5,R=.5, data seed 12345, np.random.seed(99), N=1000, T=1000."""
+    meta = golden_window.meta[0]
+    assert (meta["model"], meta["N"], meta["T"], meta["seed"]) == ("svm", 1000, 1000, 99)
+    ms = golden_window.get(meta["key"], "mean_statistic")
+    np.testing.assert_allclose(ms, [5.62738493, 9.88344914, -123.63120925], rtol=0, atol=1e-7)
+    assert abs(float(golden_window.get(meta["key"], "loglikelihood_estimate")) + 1561.7975224303605) < 1e-9
+
+
+def test_stream_order_matches_global_state():
+    """draw_streams on the global legacy state == on a RandomState with the same seed."""
+    np.random.seed(5)
+    a = po.draw_streams(np.random, 7, 3)
+    b = po.draw_streams(np.random.RandomState(5), 7, 3)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_multinomial_matches_numpy_choice():
+    rng = np.random.RandomState(3)
+    p = rng.dirichlet(np.ones(50))
+    s1 = np.random.RandomState(11)
+    idx = s1.choice(range(50), size=50, replace=True, p=p)
+    s2 = np.random.RandomState(11)
+    u = s2.random_sample(50)
+    assert np.array_equal(idx, po.multinomial_ancestors(p, u))
+    # both consumed exactly 50 doubles
+    assert s1.random_sample() == s2.random_sample()
