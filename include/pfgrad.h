@@ -1,0 +1,171 @@
+/*
+ * pfgrad.h -- C ABI of libpfgrad.so: the buffered particle-filter score / log-likelihood
+ * estimator of sgmcmc_ssm, implemented as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference is pure Python and has no FFI; this ABI is what a ctypes binding on the
+ * reference side would bind in place of the call
+ *     buffered_pf_wrapper(pf=..., observations=..., parameters=..., N=..., kernel=...,
+ *                         additive_statistic_func=..., t1=..., tL=..., weights=...,
+ *                         prior_mean=..., prior_var=...)
+ * (sgmcmc_ssm/particle_filters/buffered_smoother.py:156-199, loop :12-149) as issued by
+ * Helper.pf_gradient_estimate / pf_loglikelihood_estimate
+ * (models/svm/helper.py:67-185, models/garch/helper.py:59-170, models/lgssm/helper.py:1016-1143).
+ * Python callables (Kernel objects, additive_statistic_func) cannot cross to the device,
+ * so (Kernel, statistic) pairs are replaced by enumerated ids.  See INTEGRATION.md for the
+ * reference-side ctypes stub.
+ *
+ * Conventions: plain C, no torch types.  Every function returns 0 on success or a negative
+ * pfg_status code and never throws; the message is available from pfg_last_error().
+ * A pfg_ctx is not thread-safe (one per host thread / process).  Host pointers are owned by
+ * the caller and must stay valid for the duration of the call; device memory allocated by
+ * the library is owned by the pfg_ctx.
+ */
+#ifndef PFGRAD_H
+#define PFGRAD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFG_VERSION 100          /* 0.1.0 */
+#define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
+#define PFG_MAX_THETA 4          /* raw parameters per model */
+#define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
+
+typedef struct pfg_ctx pfg_ctx;
+
+/* models: theta layout = Parameters.var_dict order of the reference
+ *   SVM   [A, LQinv, LRinv]                       models/svm/parameters.py:21-25
+ *   GARCH [log_mu, logit_phi, logit_lambduh, LRinv] models/garch/parameters.py:19-22
+ *   LGSSM [A, C, LQinv, LRinv]                    models/lgssm/parameters.py:20-25
+ * score statistic column order (what pf_gradient_estimate unpacks):
+ *   SVM   [LRinv, LQinv, A]                       models/svm/helper.py:121-126
+ *   GARCH [LRinv, log_mu, logit_phi, logit_lambduh] models/garch/helper.py:109-115
+ *   LGSSM [LRinv, LQinv, C, A]                    models/lgssm/helper.py:1136-1142        */
+enum pfg_model { PFG_MODEL_SVM = 0, PFG_MODEL_GARCH = 1, PFG_MODEL_LGSSM = 2 };
+/* proposal kernels: models/{svm,garch,lgssm}/kernels.py ("prior" bootstrap, "optimal") */
+enum pfg_kernel { PFG_KERNEL_PRIOR = 0, PFG_KERNEL_OPTIMAL = 1 };
+/* smoothers: particle_filters/pf.py:138-181 (nemeth; poyiadjis_N = lambduh 1.0), :40-82 (filter) */
+enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1 };
+/* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
+enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2 };
+/* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
+enum pfg_dtype { PFG_F64 = 0, PFG_F32 = 1 };
+/* REPLAY: caller supplies the NumPy legacy stream (z0[N], u[T*N], z[T*N]) -> results
+ * reproduce the reference on the same seed.  PHILOX: counter-based device generator. */
+enum pfg_rng { PFG_RNG_REPLAY = 0, PFG_RNG_PHILOX = 1 };
+
+enum pfg_status {
+    PFG_OK = 0,
+    PFG_ERR_INVALID = -1,      /* bad argument (message says which) */
+    PFG_ERR_UNSUPPORTED = -2,  /* combination not built (e.g. SVM optimal kernel) */
+    PFG_ERR_DEVICE = -3,       /* HIP runtime error */
+    PFG_ERR_NOMEM = -4,
+    PFG_ERR_NUMERIC = -5       /* |A| > 1 for SVM (models/svm/kernels.py:6-11) */
+};
+
+/* flags of pfg_problem / pfg_dev_problem */
+#define PFG_FLAG_GARCH_STATIONARY_PRIOR 1u /* prior_var = alpha/(1-beta-gamma) (garch/helper.py:324-327) */
+
+/* One buffered PF window, host side (all pointers are HOST pointers, C-contiguous f64). */
+typedef struct pfg_problem {
+    int32_t model, kernel, smoother, stat, dtype, rng;
+    int32_t N;               /* particles */
+    int32_t T;               /* timesteps of the buffered window */
+    int32_t t1, tL;          /* statistic / log-likelihood accumulate on [t1, tL) */
+    uint32_t flags;
+    int32_t reserved;
+    double lambduh;          /* Nemeth shrinkage; 1.0 = Poyiadjis O(N) */
+    double prior_mean, prior_var;
+    const double *y;         /* [T] observations (m = 1) */
+    const double *weights;   /* [tL-t1] importance weights or NULL (= 1) */
+    const double *theta;     /* raw parameters, model layout above */
+    const double *z0, *u, *z;/* REPLAY streams: [N], [T*N], [T*N]; NULL for PHILOX */
+    uint64_t seed, stream;   /* PHILOX key and stream id */
+    const double *init_x, *init_logw, *init_stats; /* optional warm start: [N*n],[N],[N*h] */
+} pfg_problem;
+
+/* Result of one window; optional arrays are caller-allocated HOST buffers or NULL. */
+typedef struct pfg_result {
+    double mean_stat[PFG_MAX_STAT]; /* sum_i stats_i softmax(logw)_i (average_statistic); FILTER: running m */
+    double loglik;                  /* loglikelihood_estimate */
+    double *x_T;        /* [N*n]  final particles          */
+    double *logw_T;     /* [N]    final log weights        */
+    double *stats_T;    /* [N*h]  final per-particle statistics (NEMETH only) */
+    double *trace_x;    /* [(T+1)*N*n]  = save_all 'all_x_t'            */
+    double *trace_logw; /* [(T+1)*N]    = 'all_log_weights'             */
+    double *trace_stats;/* [(T+1)*N*h]  = 'all_statistics' (NEMETH)     */
+    double *trace_ll;   /* [T+1]        = 'all_loglikelihood_estimate'  */
+    int32_t status;
+    int32_t reserved;
+} pfg_result;
+
+/* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
+ * pointers.  Used by pfg_launch_device() for callers that keep everything resident
+ * (multi-chain SGLD engine, bench).  Layout is part of the ABI (Python mirrors it). */
+typedef struct pfg_dev_problem {
+    const double *y;
+    const double *weights;
+    const double *theta;
+    const double *z0, *u, *z;
+    const double *init_x, *init_logw, *init_stats;
+    double *out;             /* [PFG_OUT_DOUBLES]: mean_stat[0..3], loglik, sum of weights W_T,
+                                max log weight m_T, min |u - cdf| tie margin (REPLAY) */
+    double *final_x, *final_logw, *final_stats;
+    double *trace_x, *trace_logw, *trace_stats, *trace_ll;
+    const uint64_t *step_ctr;/* optional: *step_ctr is mixed into the PHILOX counter */
+    void *scratch;           /* large-N variant: per-problem state buffers, else NULL */
+    double prior_mean, prior_var, lambduh;
+    uint64_t seed, stream;
+    int32_t T, t1, tL, N;
+    int32_t smoother, stat;
+    uint32_t flags;
+    int32_t reserved;
+} pfg_dev_problem;
+
+int pfg_version(void);
+/* sizeof() of an ABI struct: 0 pfg_problem, 1 pfg_result, 2 pfg_dev_problem, 3 pfg_prior_hyper
+ * (bindings assert their mirror has the same size) */
+int pfg_struct_size(int which);
+int pfg_create(pfg_ctx **out, int device_id);
+void pfg_destroy(pfg_ctx *ctx);
+const char *pfg_last_error(pfg_ctx *ctx);   /* ctx may be NULL: last error of pfg_create */
+
+/* Host-buffer entry points: stage inputs to HBM, run, copy results back, synchronise.
+ * pfg_run_batch requires all problems to share model/kernel/dtype/rng; N, T, windows,
+ * parameters and seeds may differ per problem.  One workgroup per problem. */
+int pfg_run(pfg_ctx *ctx, const pfg_problem *p, pfg_result *r);
+int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs);
+
+/* Resident entry point: `dev_probs` is a DEVICE array of B descriptors; launches on
+ * `hip_stream` (a hipStream_t, NULL = the ctx stream) and returns without synchronising.
+ * n_max = the largest N in the batch (selects the kernel variant). */
+int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
+                      int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+/* bytes of per-problem scratch the large-N variant needs for (model, dtype, N); 0 if the
+ * LDS-resident variant serves this size */
+int64_t pfg_scratch_bytes(int model, int dtype, int N);
+/* name of the kernel variant pfg_launch_device would pick (for profiles / logs) */
+const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max);
+int pfg_synchronize(pfg_ctx *ctx);
+
+/* SGLD parameter update for B resident chains (sgmcmc_sampler.py:427-464, 529-566, 650-656):
+ *   theta_v += eps*(grad_logprior_v(theta) + ghat_v)/Tscale + sqrt(2 eps) N(0, 1/Tscale)
+ * followed by project_parameters.  `outs` is the [B][PFG_OUT_DOUBLES] result array the
+ * PF kernel wrote (score column order), `theta` [B][PFG_MAX_THETA] is updated in place.
+ * hyper: model-specific prior hyper-parameters, see pfg_prior_hyper. */
+typedef struct pfg_prior_hyper {
+    double df_Qinv, scale_Qinv, df_Rinv, scale_Rinv;  /* Wishart on Qinv/Rinv (covariance.py:252-284) */
+    double mean_A, var_col_A, mean_C, var_col_C;      /* matrix normal (matrices.py:597-607) */
+    double scale_mu, shape_mu, alpha_phi, beta_phi, alpha_lambduh, beta_lambduh; /* garch_var.py:152-165 */
+} pfg_prior_hyper;
+int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
+                           const pfg_prior_hyper *hyper, double epsilon, double Tscale,
+                           uint64_t seed, uint64_t *step_ctr, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFGRAD_H */

@@ -1,0 +1,468 @@
+// libpfgrad.so: host side of the C ABI declared in include/pfgrad.h + kernel dispatch.
+// Build: see csrc/build.sh (hipcc --offload-arch=gfx950 -ffp-contract=off -shared -fPIC).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pfgrad.h"
+#include "pfg_device.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Arena {           // growable device buffer
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct pfg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Arena in, out, desc;
+    std::vector<double> h_in, h_out;
+    std::vector<pfg_dev_problem> h_desc;
+};
+
+namespace {
+
+int fail(pfg_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PFG_HIP(ctx, call)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PFG_ERR_NOMEM : PFG_ERR_DEVICE, \
+                        std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+// ---- kernel variants ----------------------------------------------------------------
+struct Variant { int NT, PPT; const char *tag; };
+const Variant kVariants[] = { {256, 1, "wg256x1"}, {256, 4, "wg256x4"}, {1024, 4, "wg1024x4"} };
+constexpr size_t kLdsLimit = 160 * 1024;
+
+int state_dim(int model) { return model == PFG_MODEL_GARCH ? 2 : 1; }
+int stat_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
+int theta_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
+
+size_t lds_bytes(int model, int dtype, int NT, int PPT, int N) {
+    size_t rs = dtype == PFG_F64 ? 8 : 4;
+    size_t NL = (size_t)(N + 63) / 64 * 64;
+    size_t red = (size_t)PPT * (NT / 64) + (NT / 64) + (size_t)PFG_MAX_STAT * (NT / 64) + 8;
+    return NL * 8 + NL * (state_dim(model) + stat_dim(model)) * rs + red * 8;
+}
+
+// index into kVariants, or -1 when no LDS-resident variant fits
+int pick_variant(int model, int dtype, int n_max) {
+    for (int v = 0; v < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++v) {
+        if (n_max <= kVariants[v].NT * kVariants[v].PPT &&
+            lds_bytes(model, dtype, kVariants[v].NT, kVariants[v].PPT, n_max) <= kLdsLimit)
+            return v;
+    }
+    return -1;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    switch (v) {
+        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
+        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
+        case 2: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG>(ctx, n_max, B, dp, st);
+    }
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
+}
+
+template <int MODEL, int KERNEL>
+int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
+              hipStream_t st) {
+    if (dtype == PFG_F64) {
+        if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
+        return launch_v<MODEL, KERNEL, double, PFG_RNG_PHILOX>(ctx, v, n_max, B, dp, st);
+    }
+    if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
+    return launch_v<MODEL, KERNEL, float, PFG_RNG_PHILOX>(ctx, v, n_max, B, dp, st);
+}
+
+int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
+    if (model < 0 || model > 2) return fail(ctx, PFG_ERR_INVALID, "Unrecognized model id");
+    if (kernel != PFG_KERNEL_PRIOR && kernel != PFG_KERNEL_OPTIMAL)
+        return fail(ctx, PFG_ERR_INVALID, "Unrecoginized kernel id");
+    if (model == PFG_MODEL_SVM && kernel == PFG_KERNEL_OPTIMAL)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "SVM optimal kernel not analytic");   // svm/helper.py:62
+    if (dtype != PFG_F64 && dtype != PFG_F32) return fail(ctx, PFG_ERR_INVALID, "bad dtype");
+    if (rng != PFG_RNG_REPLAY && rng != PFG_RNG_PHILOX) return fail(ctx, PFG_ERR_INVALID, "bad rng mode");
+    return PFG_OK;
+}
+
+int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
+             const pfg_dev_problem *dp, hipStream_t st) {
+    int rc = check_combo(ctx, model, kernel, dtype, rng);
+    if (rc) return rc;
+    if (B <= 0) return PFG_OK;
+    if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
+    int v = pick_variant(model, dtype, n_max);
+    if (v < 0)
+        return fail(ctx, PFG_ERR_UNSUPPORTED,
+                    "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
+    if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
+    if (model == PFG_MODEL_GARCH) {
+        if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
+        return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st);
+    }
+    if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
+    return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st);
+}
+
+// ---- SGLD update for resident chains ---------------------------------------------------
+__device__ __forceinline__ double reflect_chol(double L) { return L < 0.0 ? sqrt(L * L + 1e-16) : L; }
+
+__global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
+                                   const double *__restrict__ outs, pfg_prior_hyper hy, double eps,
+                                   double Tscale, uint64_t seed, const uint64_t *step_ctr) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double *th = theta + (size_t)b * PFG_MAX_THETA;
+    const double *g = outs + (size_t)b * PFG_OUT_DOUBLES;
+    const uint64_t step = step_ctr ? *step_ctr : 0ull;
+    pfg::u32x4 r0 = pfg::philox4x32_10({(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5A11u},
+                                       (uint32_t)seed, (uint32_t)(seed >> 32));
+    pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5A12u},
+                                       (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps);
+    double nz[4] = {pfg::normal_bm<double>(r0.x, r0.y), pfg::normal_bm<double>(r0.z, r0.w),
+                    pfg::normal_bm<double>(r1.x, r1.y), pfg::normal_bm<double>(r1.z, r1.w)};
+    if (model == PFG_MODEL_SVM || model == PFG_MODEL_LGSSM) {
+        const bool lg = model == PFG_MODEL_LGSSM;
+        double A = th[0], C = lg ? th[1] : 1.0, LQ = th[lg ? 2 : 1], LR = th[lg ? 3 : 2];
+        double Qinv = LQ * LQ + 1e-16, Rinv = LR * LR + 1e-16;
+        // score columns: SVM [LR, LQ, A]; LGSSM [LR, LQ, C, A]
+        double gLR = g[0], gLQ = g[1], gC = lg ? g[2] : 0.0, gA = g[lg ? 3 : 2];
+        // grad_logprior: covariance.py:272-284 (n = 1), matrices.py:597-607
+        double pLQ = (hy.df_Qinv - 2.0) / LQ - LQ / hy.scale_Qinv;
+        double pLR = (hy.df_Rinv - 2.0) / LR - LR / hy.scale_Rinv;
+        double pA = -1.0 * (Qinv * (A - hy.mean_A)) / hy.var_col_A;
+        double pC = -1.0 * (Rinv * (C - hy.mean_C)) / hy.var_col_C;
+        int j = 0;
+        A += eps * ((pA + gA) / Tscale) + nsd * nz[j++];
+        if (lg) C += eps * ((pC + gC) / Tscale) + nsd * nz[j++];
+        LQ += eps * ((pLQ + gLQ) / Tscale) + nsd * nz[j++];
+        LR += eps * ((pLR + gLR) / Tscale) + nsd * nz[j++];
+        // project_parameters: _utils.py:165-170, covariance.py:68-80, lgssm/parameters.py:39-42
+        double aa = fabs(A);
+        if (aa > 0.9999) A *= 0.9999 / aa;
+        if (lg) C = 1.0;
+        LQ = reflect_chol(LQ); LR = reflect_chol(LR);
+        th[0] = A;
+        if (lg) { th[1] = C; th[2] = LQ; th[3] = LR; } else { th[1] = LQ; th[2] = LR; }
+    } else {
+        double lmu = th[0], lphi = th[1], llam = th[2], LR = th[3];
+        double mu = exp(lmu), phi = 1.0 / (1.0 + exp(-lphi)), lam = 1.0 / (1.0 + exp(-llam));
+        // garch_var.py:152-165
+        double p0 = -hy.shape_mu - 1.0 + hy.scale_mu / mu;
+        double p1 = ((hy.alpha_phi - 1.0) / (1.0 + phi) - (hy.beta_phi - 1.0) / (1.0 - phi)) * phi * (1.0 - phi);
+        double p2 = ((hy.alpha_lambduh - 1.0) / (1.0 + lam) - (hy.beta_lambduh - 1.0) / (1.0 - lam)) * lam * (1.0 - lam);
+        double pLR = (hy.df_Rinv - 2.0) / LR - LR / hy.scale_Rinv;
+        // score columns [LR, log_mu, logit_phi, logit_lambduh]
+        lmu += eps * ((p0 + g[1]) / Tscale) + nsd * nz[0];
+        lphi += eps * ((p1 + g[2]) / Tscale) + nsd * nz[1];
+        llam += eps * ((p2 + g[3]) / Tscale) + nsd * nz[2];
+        LR += eps * ((pLR + g[0]) / Tscale) + nsd * nz[3];
+        th[0] = lmu; th[1] = lphi; th[2] = llam; th[3] = reflect_chol(LR);
+    }
+}
+
+__global__ void bump_counter_kernel(uint64_t *ctr) { *ctr += 1; }
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+int pfg_version(void) { return PFG_VERSION; }
+
+int pfg_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(pfg_problem);
+        case 1: return (int)sizeof(pfg_result);
+        case 2: return (int)sizeof(pfg_dev_problem);
+        case 3: return (int)sizeof(pfg_prior_hyper);
+    }
+    return -1;
+}
+
+const char *pfg_last_error(pfg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pfg_create(pfg_ctx **out, int device_id) {
+    if (!out) return fail(nullptr, PFG_ERR_INVALID, "pfg_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PFG_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, PFG_ERR_INVALID, "pfg_create: bad device id");
+    pfg_ctx *ctx = new (std::nothrow) pfg_ctx();
+    if (!ctx) return fail(nullptr, PFG_ERR_NOMEM, "pfg_create: out of host memory");
+    ctx->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        std::string m = std::string("pfg_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, PFG_ERR_DEVICE, m);
+    }
+    *out = ctx;
+    return PFG_OK;
+}
+
+void pfg_destroy(pfg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    ctx->in.release(); ctx->out.release(); ctx->desc.release();
+    delete ctx;
+}
+
+int pfg_synchronize(pfg_ctx *ctx) {
+    if (!ctx) return PFG_ERR_INVALID;
+    PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PFG_OK;
+}
+
+int64_t pfg_scratch_bytes(int model, int dtype, int N) {
+    if (pick_variant(model, dtype, N) >= 0) return 0;
+    return -1;   // large-N variant not built yet
+}
+
+const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max) {
+    (void)kernel; (void)rng;
+    int v = pick_variant(model, dtype, n_max);
+    return v < 0 ? "none" : kVariants[v].tag;
+}
+
+int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
+                      const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device: dev_probs is NULL");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, st);
+}
+
+int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
+                           const pfg_prior_hyper *hyper, double epsilon, double Tscale, uint64_t seed,
+                           uint64_t *step_ctr, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!theta || !outs || !hyper) return fail(ctx, PFG_ERR_INVALID, "pfg_sgld_update_device: NULL argument");
+    if (model < 0 || model > 2) return fail(ctx, PFG_ERR_INVALID, "Unrecognized model id");
+    if (!(epsilon > 0.0) || !(Tscale > 0.0)) return fail(ctx, PFG_ERR_INVALID, "epsilon and Tscale must be > 0");
+    if (B <= 0) return PFG_OK;
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipLaunchKernelGGL(sgld_update_kernel, dim3((B + 127) / 128), dim3(128), 0, st, model, B, theta, outs,
+                       *hyper, epsilon, Tscale, seed, (const uint64_t *)step_ctr);
+    if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+int pfg_run(pfg_ctx *ctx, const pfg_problem *p, pfg_result *r) { return pfg_run_batch(ctx, 1, p, r); }
+
+int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (B < 0 || (B > 0 && (!ps || !rs))) return fail(ctx, PFG_ERR_INVALID, "pfg_run_batch: NULL problems/results");
+    if (B == 0) return PFG_OK;
+    const int model = ps[0].model, kernel = ps[0].kernel, dtype = ps[0].dtype, rng = ps[0].rng;
+    int rc = check_combo(ctx, model, kernel, dtype, rng);
+    if (rc) return rc;
+    const int NS = state_dim(model), H = stat_dim(model), P = theta_dim(model);
+
+    // ---- validate + size ------------------------------------------------------------
+    size_t n_in = 0, n_out = 0;
+    int n_max = 0;
+    for (int b = 0; b < B; ++b) {
+        const pfg_problem &q = ps[b];
+        std::string id = "problem " + std::to_string(b) + ": ";
+        if (q.model != model || q.kernel != kernel || q.dtype != dtype || q.rng != rng)
+            return fail(ctx, PFG_ERR_INVALID, id + "model/kernel/dtype/rng must match across a batch");
+        if (q.N < 1) return fail(ctx, PFG_ERR_INVALID, id + "N must be >= 1");
+        if (q.T < 0) return fail(ctx, PFG_ERR_INVALID, id + "T must be >= 0");
+        if (q.t1 < 0 || q.tL < q.t1) return fail(ctx, PFG_ERR_INVALID, id + "need 0 <= t1 <= tL");
+        if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_FILTER)
+            return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
+        if (q.stat < PFG_STAT_SCORE || q.stat > PFG_STAT_NONE) return fail(ctx, PFG_ERR_INVALID, id + "bad stat id");
+        if (!q.theta) return fail(ctx, PFG_ERR_INVALID, id + "theta is NULL");
+        if (q.T > 0 && !q.y) return fail(ctx, PFG_ERR_INVALID, id + "observations are NULL");
+        if (rng == PFG_RNG_REPLAY && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
+        if (rng == PFG_RNG_REPLAY && q.T > 0 && (!q.u || !q.z)) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs u and z");
+        if (q.init_x && !q.init_logw) return fail(ctx, PFG_ERR_INVALID, id + "init_x needs init_logw");
+        if (!(q.prior_var >= 0.0) && !(q.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR) && !q.init_x)
+            return fail(ctx, PFG_ERR_INVALID, id + "prior_var must be >= 0");
+        if (model == PFG_MODEL_SVM && std::fabs(q.theta[0]) > 1.0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "Current AR parameter is |A| = %.17g > 1\nTry calling project_parameters?",
+                     std::fabs(q.theta[0]));
+            return fail(ctx, PFG_ERR_NUMERIC, buf);                                   // svm/kernels.py:6-11
+        }
+        n_max = q.N > n_max ? q.N : n_max;
+        const int nw = q.weights ? (q.tL < q.T ? q.tL : q.T) - q.t1 : 0;
+        n_in += (size_t)q.T + (nw > 0 ? nw : 0) + PFG_MAX_THETA;
+        if (rng == PFG_RNG_REPLAY) n_in += (q.z0 ? (size_t)q.N : 0) + 2 * (size_t)q.T * q.N;
+        if (q.init_x) n_in += (size_t)q.N * (NS + 1) + (q.init_stats ? (size_t)q.N * H : 0);
+        const pfg_result &r = rs[b];
+        n_out += PFG_OUT_DOUBLES;
+        if (r.x_T) n_out += (size_t)q.N * NS;
+        if (r.logw_T) n_out += q.N;
+        if (r.stats_T) n_out += (size_t)q.N * H;
+        if (r.trace_x) n_out += (size_t)(q.T + 1) * q.N * NS;
+        if (r.trace_logw) n_out += (size_t)(q.T + 1) * q.N;
+        if (r.trace_stats) n_out += (size_t)(q.T + 1) * q.N * H;
+        if (r.trace_ll) n_out += (size_t)q.T + 1;
+        if ((r.logw_T || r.stats_T) && !r.x_T) return fail(ctx, PFG_ERR_INVALID, id + "logw_T/stats_T need x_T");
+        if ((r.trace_logw == nullptr) != (r.trace_x == nullptr))
+            return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
+        if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
+    }
+    if (pick_variant(model, dtype, n_max) < 0)
+        return fail(ctx, PFG_ERR_UNSUPPORTED,
+                    "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
+
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    PFG_HIP(ctx, ctx->in.ensure(n_in * 8));
+    PFG_HIP(ctx, ctx->out.ensure(n_out * 8));
+    PFG_HIP(ctx, ctx->desc.ensure((size_t)B * sizeof(pfg_dev_problem)));
+    try {
+        ctx->h_in.resize(n_in);
+        ctx->h_out.resize(n_out);
+        ctx->h_desc.assign(B, pfg_dev_problem{});
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, PFG_ERR_NOMEM, "pfg_run_batch: out of host memory");
+    }
+
+    // ---- pack ---------------------------------------------------------------------------
+    double *hin = ctx->h_in.data();
+    const double *din = static_cast<const double *>(ctx->in.ptr);
+    double *dout = static_cast<double *>(ctx->out.ptr);
+    size_t oi = 0, oo = 0;
+    auto put = [&](const double *src, size_t n) -> const double * {
+        if (!src || n == 0) return nullptr;
+        std::memcpy(hin + oi, src, n * 8);
+        const double *d = din + oi;
+        oi += n;
+        return d;
+    };
+    auto take = [&](bool want, size_t n) -> double * {
+        if (!want) return nullptr;
+        double *d = dout + oo;
+        oo += n;
+        return d;
+    };
+    for (int b = 0; b < B; ++b) {
+        const pfg_problem &q = ps[b];
+        const pfg_result &r = rs[b];
+        pfg_dev_problem &d = ctx->h_desc[b];
+        const int tL = q.tL < q.T ? q.tL : q.T;
+        const int nw = q.weights ? tL - q.t1 : 0;
+        d.y = put(q.y, q.T);
+        d.weights = put(q.weights, nw > 0 ? nw : 0);
+        {
+            double th[PFG_MAX_THETA] = {0, 0, 0, 0};
+            for (int j = 0; j < P; ++j) th[j] = q.theta[j];
+            d.theta = put(th, PFG_MAX_THETA);
+        }
+        if (rng == PFG_RNG_REPLAY) {
+            d.z0 = put(q.z0, q.z0 ? q.N : 0);
+            d.u = put(q.u, (size_t)q.T * q.N);
+            d.z = put(q.z, (size_t)q.T * q.N);
+        }
+        if (q.init_x) {
+            d.init_x = put(q.init_x, (size_t)q.N * NS);
+            d.init_logw = put(q.init_logw, q.N);
+            d.init_stats = put(q.init_stats, q.init_stats ? (size_t)q.N * H : 0);
+        }
+        d.out = take(true, PFG_OUT_DOUBLES);
+        d.final_x = take(r.x_T != nullptr, (size_t)q.N * NS);
+        d.final_logw = take(r.logw_T != nullptr, q.N);
+        d.final_stats = take(r.stats_T != nullptr, (size_t)q.N * H);
+        d.trace_x = take(r.trace_x != nullptr, (size_t)(q.T + 1) * q.N * NS);
+        d.trace_logw = take(r.trace_logw != nullptr, (size_t)(q.T + 1) * q.N);
+        d.trace_stats = take(r.trace_stats != nullptr, (size_t)(q.T + 1) * q.N * H);
+        d.trace_ll = take(r.trace_ll != nullptr, (size_t)q.T + 1);
+        d.step_ctr = nullptr;
+        d.scratch = nullptr;
+        d.prior_mean = q.prior_mean; d.prior_var = q.prior_var; d.lambduh = q.lambduh;
+        d.seed = q.seed; d.stream = q.stream;
+        d.T = q.T; d.t1 = q.t1; d.tL = tL; d.N = q.N;
+        d.smoother = q.smoother; d.stat = q.stat; d.flags = q.flags;
+    }
+
+    // ---- stage, launch, fetch -----------------------------------------------------------
+    PFG_HIP(ctx, hipMemcpyAsync(ctx->in.ptr, hin, oi * 8, hipMemcpyHostToDevice, ctx->stream));
+    PFG_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->h_desc.data(), (size_t)B * sizeof(pfg_dev_problem),
+                                hipMemcpyHostToDevice, ctx->stream));
+    PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
+    rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
+                  ctx->stream);
+    if (rc) return rc;
+    PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    const double *hout = ctx->h_out.data();
+    for (int b = 0; b < B; ++b) {
+        const pfg_problem &q = ps[b];
+        pfg_result &r = rs[b];
+        const pfg_dev_problem &d = ctx->h_desc[b];
+        auto host_of = [&](const double *dev) { return hout + (dev - dout); };
+        const double *o = host_of(d.out);
+        for (int h = 0; h < PFG_MAX_STAT; ++h) r.mean_stat[h] = o[h];
+        r.loglik = o[4];
+        auto fetch = [&](double *dst, const double *dev, size_t n) {
+            if (dst && dev) std::memcpy(dst, host_of(dev), n * 8);
+        };
+        fetch(r.x_T, d.final_x, (size_t)q.N * NS);
+        fetch(r.logw_T, d.final_logw, q.N);
+        fetch(r.stats_T, d.final_stats, (size_t)q.N * H);
+        fetch(r.trace_x, d.trace_x, (size_t)(q.T + 1) * q.N * NS);
+        fetch(r.trace_logw, d.trace_logw, (size_t)(q.T + 1) * q.N);
+        fetch(r.trace_stats, d.trace_stats, (size_t)(q.T + 1) * q.N * H);
+        fetch(r.trace_ll, d.trace_ll, (size_t)q.T + 1);
+        r.status = PFG_OK;
+    }
+    return PFG_OK;
+}
+
+}  // extern "C"

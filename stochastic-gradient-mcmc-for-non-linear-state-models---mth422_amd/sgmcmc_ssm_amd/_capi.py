@@ -1,0 +1,293 @@
+"""ctypes binding of libpfgrad.so (include/pfgrad.h).
+
+This is the only door from Python to the particle-filter kernels.  There is no CPU
+fallback: if the library is missing or no MI355X is visible the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+# ---- enums (include/pfgrad.h) ---------------------------------------------------------
+MODEL = {"svm": 0, "garch": 1, "lgssm": 2}
+KERNEL = {"prior": 0, "optimal": 1}
+SMOOTHER = {"nemeth": 0, "filter": 1}
+STAT = {"score": 0, "suff": 1, "none": 2}
+DTYPE = {"f64": 0, "f32": 1}
+RNG = {"replay": 0, "philox": 1}
+FLAG_GARCH_STATIONARY_PRIOR = 1
+MAX_STAT, MAX_THETA, OUT_DOUBLES = 4, 4, 8
+STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
+STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
+THETA_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
+
+PFG_OK, PFG_ERR_INVALID, PFG_ERR_UNSUPPORTED, PFG_ERR_DEVICE, PFG_ERR_NOMEM, PFG_ERR_NUMERIC = 0, -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("kernel", C.c_int32), ("smoother", C.c_int32), ("stat", C.c_int32),
+        ("dtype", C.c_int32), ("rng", C.c_int32),
+        ("N", C.c_int32), ("T", C.c_int32), ("t1", C.c_int32), ("tL", C.c_int32),
+        ("flags", C.c_uint32), ("reserved", C.c_int32),
+        ("lambduh", C.c_double), ("prior_mean", C.c_double), ("prior_var", C.c_double),
+        ("y", _dp), ("weights", _dp), ("theta", _dp),
+        ("z0", _dp), ("u", _dp), ("z", _dp),
+        ("seed", C.c_uint64), ("stream", C.c_uint64),
+        ("init_x", _dp), ("init_logw", _dp), ("init_stats", _dp),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("mean_stat", C.c_double * MAX_STAT), ("loglik", C.c_double),
+        ("x_T", _dp), ("logw_T", _dp), ("stats_T", _dp),
+        ("trace_x", _dp), ("trace_logw", _dp), ("trace_stats", _dp), ("trace_ll", _dp),
+        ("status", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PriorHyper(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "df_Qinv", "scale_Qinv", "df_Rinv", "scale_Rinv",
+        "mean_A", "var_col_A", "mean_C", "var_col_C",
+        "scale_mu", "shape_mu", "alpha_phi", "beta_phi", "alpha_lambduh", "beta_lambduh")]
+
+
+# numpy mirror of pfg_dev_problem (device descriptors are built on the host as a structured
+# array and uploaded; all pointer fields are device addresses)
+DEV_PROBLEM_DTYPE = np.dtype([
+    ("y", "u8"), ("weights", "u8"), ("theta", "u8"),
+    ("z0", "u8"), ("u", "u8"), ("z", "u8"),
+    ("init_x", "u8"), ("init_logw", "u8"), ("init_stats", "u8"),
+    ("out", "u8"),
+    ("final_x", "u8"), ("final_logw", "u8"), ("final_stats", "u8"),
+    ("trace_x", "u8"), ("trace_logw", "u8"), ("trace_stats", "u8"), ("trace_ll", "u8"),
+    ("step_ctr", "u8"), ("scratch", "u8"),
+    ("prior_mean", "f8"), ("prior_var", "f8"), ("lambduh", "f8"),
+    ("seed", "u8"), ("stream", "u8"),
+    ("T", "i4"), ("t1", "i4"), ("tL", "i4"), ("N", "i4"),
+    ("smoother", "i4"), ("stat", "i4"), ("flags", "u4"), ("reserved", "i4"),
+], align=True)
+
+EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
+           "pfg_launch_device", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
+           "pfg_sgld_update_device")
+
+_lib = None
+
+
+class PfgError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libpfgrad error {0}: {1}".format(code, message))
+        self.code = code
+        self.message = message
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree libpfgrad.so (never builds implicitly on a GPU box: build() does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libpfgrad.so is not built ({0}). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python -m sgmcmc_ssm_amd._build`; there is no CPU fallback.".format(path))
+    lib = C.CDLL(path)
+    lib.pfg_version.restype = C.c_int
+    lib.pfg_struct_size.argtypes = [C.c_int]
+    lib.pfg_struct_size.restype = C.c_int
+    sizes = (C.sizeof(Problem), C.sizeof(Result), DEV_PROBLEM_DTYPE.itemsize, C.sizeof(PriorHyper))
+    for which, mine in enumerate(sizes):
+        if lib.pfg_struct_size(which) != mine:
+            raise RuntimeError("ABI mismatch: struct {0} is {1} bytes in libpfgrad.so, {2} in the binding"
+                               .format(which, lib.pfg_struct_size(which), mine))
+    lib.pfg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.pfg_create.restype = C.c_int
+    lib.pfg_destroy.argtypes = [C.c_void_p]
+    lib.pfg_destroy.restype = None
+    lib.pfg_last_error.argtypes = [C.c_void_p]
+    lib.pfg_last_error.restype = C.c_char_p
+    lib.pfg_run.argtypes = [C.c_void_p, C.POINTER(Problem), C.POINTER(Result)]
+    lib.pfg_run.restype = C.c_int
+    lib.pfg_run_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Result)]
+    lib.pfg_run_batch.restype = C.c_int
+    lib.pfg_launch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    lib.pfg_launch_device.restype = C.c_int
+    lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.pfg_scratch_bytes.restype = C.c_int64
+    lib.pfg_variant_name.argtypes = [C.c_int] * 5
+    lib.pfg_variant_name.restype = C.c_char_p
+    lib.pfg_synchronize.argtypes = [C.c_void_p]
+    lib.pfg_synchronize.restype = C.c_int
+    lib.pfg_sgld_update_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.POINTER(PriorHyper), C.c_double, C.c_double, C.c_uint64,
+                                           C.c_void_p, C.c_void_p]
+    lib.pfg_sgld_update_device.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Context:
+    """One pfg_ctx (one per process / GPU). Not thread-safe."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.pfg_create(C.byref(h), int(device_id))
+        if rc != 0:
+            msg = self.lib.pfg_last_error(None).decode()
+            raise PfgError(rc, msg + " (the HIP particle-filter path needs an MI355X; there is no CPU fallback)")
+        self.handle = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pfg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.pfg_last_error(self.handle).decode()
+            if rc == PFG_ERR_NUMERIC:
+                raise ValueError(msg)
+            if rc == PFG_ERR_UNSUPPORTED:
+                raise NotImplementedError(msg)
+            if rc == PFG_ERR_INVALID:
+                raise ValueError(msg)
+            raise PfgError(rc, msg)
+
+    # ---- host-buffer path ----------------------------------------------------------------
+    def run_batch(self, problems, want_final=False, want_trace=False):
+        """problems: list of dicts with keys
+             model, kernel, smoother, stat, dtype, rng (strings), N, T (implied by y), t1, tL,
+             lambduh, prior_mean, prior_var, flags, y, weights, theta, z0,u,z | seed,stream,
+             init_x, init_logw, init_stats
+           returns list of dicts(mean_stat, loglik[, x_t, log_weights, statistics, all_*])."""
+        B = len(problems)
+        if B == 0:
+            return []
+        ps = (Problem * B)()
+        rs = (Result * B)()
+        keep = []           # keep numpy buffers alive for the duration of the call
+        outs = []
+        for b, q in enumerate(problems):
+            model = q["model"]
+            ns, h = STATE_DIM[model], STAT_DIM[model]
+            y = _as_f64(q["y"]).reshape(-1)
+            T, N = y.shape[0], int(q["N"])
+            p = ps[b]
+            p.model, p.kernel = MODEL[model], KERNEL[q["kernel"]]
+            p.smoother, p.stat = SMOOTHER[q.get("smoother", "nemeth")], STAT[q.get("stat", "score")]
+            p.dtype, p.rng = DTYPE[q.get("dtype", "f64")], RNG[q.get("rng", "replay")]
+            p.N, p.T = N, T
+            p.t1 = int(q.get("t1", 0))
+            tL = q.get("tL", None)
+            p.tL = T if tL is None else int(tL)
+            p.flags = int(q.get("flags", 0))
+            p.lambduh = float(q.get("lambduh", 1.0))
+            p.prior_mean = float(q.get("prior_mean", 0.0))
+            p.prior_var = float(q.get("prior_var", 1.0))
+            theta = _as_f64(q["theta"]).reshape(-1)
+            arrs = dict(y=y, theta=theta)
+            for name in ("weights", "z0", "u", "z", "init_x", "init_logw", "init_stats"):
+                v = q.get(name, None)
+                arrs[name] = None if v is None else _as_f64(v).reshape(-1)
+            if arrs["weights"] is not None and arrs["weights"].shape[0] < p.tL - p.t1:
+                raise ValueError("weights shorter than tL - t1")
+            if p.rng == RNG["replay"]:
+                if arrs["u"] is None or arrs["z"] is None or arrs["u"].shape[0] != T * N or arrs["z"].shape[0] != T * N:
+                    raise ValueError("replay streams u, z must have T*N entries")
+                if arrs["init_x"] is None and (arrs["z0"] is None or arrs["z0"].shape[0] != N):
+                    raise ValueError("replay stream z0 must have N entries")
+            for name, a in arrs.items():
+                setattr(p, name, _ptr(a))
+            p.seed = int(q.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
+            p.stream = int(q.get("stream", 0)) & 0xFFFFFFFFFFFFFFFF
+            keep.append(arrs)
+            o = {}
+            r = rs[b]
+            is_filter = p.smoother == SMOOTHER["filter"]
+            if want_final or want_trace:
+                o["x_t"] = np.zeros((N, ns))
+                o["log_weights"] = np.zeros(N)
+                r.x_T, r.logw_T = _ptr(o["x_t"]), _ptr(o["log_weights"])
+                if not is_filter:
+                    o["statistics"] = np.zeros((N, h))
+                    r.stats_T = _ptr(o["statistics"])
+            if want_trace:
+                o["all_x_t"] = np.zeros((T + 1, N, ns))
+                o["all_log_weights"] = np.zeros((T + 1, N))
+                o["all_loglikelihood_estimate"] = np.zeros(T + 1)
+                r.trace_x, r.trace_logw = _ptr(o["all_x_t"]), _ptr(o["all_log_weights"])
+                r.trace_ll = _ptr(o["all_loglikelihood_estimate"])
+                if not is_filter:
+                    o["all_statistics"] = np.zeros((T + 1, N, h))
+                    r.trace_stats = _ptr(o["all_statistics"])
+            outs.append(o)
+        self._check(self.lib.pfg_run_batch(self.handle, B, ps, rs))
+        for b, o in enumerate(outs):
+            # the device record is STAT_DIM[model] wide; sufficient statistics use 3 columns
+            h = 3 if problems[b].get("stat", "score") != "score" else STAT_DIM[problems[b]["model"]]
+            o["mean_stat"] = np.array(rs[b].mean_stat[:h])
+            o["loglik"] = float(rs[b].loglik)
+            for name in ("statistics", "all_statistics"):
+                if name in o:
+                    o[name] = o[name][..., :h]
+        del keep
+        return outs
+
+    # ---- resident path ---------------------------------------------------------------------
+    def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=None):
+        self._check(self.lib.pfg_launch_device(self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype],
+                                               RNG[rng], int(n_max), int(B), C.c_void_p(dev_probs_ptr),
+                                               C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sgld_update_device(self, model, B, theta_ptr, outs_ptr, hyper, epsilon, Tscale, seed,
+                           step_ctr_ptr=None, stream_ptr=None):
+        self._check(self.lib.pfg_sgld_update_device(
+            self.handle, MODEL[model], int(B), C.c_void_p(theta_ptr), C.c_void_p(outs_ptr), C.byref(hyper),
+            float(epsilon), float(Tscale), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
+            C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def variant_name(self, model, kernel, dtype, rng, n_max):
+        return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()
+
+    def synchronize(self):
+        self._check(self.lib.pfg_synchronize(self.handle))
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=None):
+    """Process-wide context for `device_id` (default: LOCAL_RANK or 0)."""
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]
