@@ -1,0 +1,248 @@
+"""ChainEnsemble: many independent SGLD chains resident on one MI355X.
+
+The reference runs one chain in one Python thread; its experiment grid fans chains / settings
+out over processes (driver_utils.py:69-111).  On an MI355X one chain keeps one workgroup (one
+of 256 CUs) busy, so the native unit of work is an *ensemble*: C chains advance in lock-step,
+each SGLD step = ONE particle-filter launch (one workgroup per chain x window) + ONE tiny
+update kernel (prior gradient, 1/T scaling, Langevin noise, projection).  Everything --
+observations, parameters, descriptors, RNG counters, results -- stays in HBM between steps;
+the host only enqueues launches.  PyTorch is used for device memory, streams and
+`torch.distributed` (RCCL) only.
+
+Multi-GPU: chains are independent, so rank r owns chains [r*C, (r+1)*C) (weak scaling) and
+the only collective is the gather of the parameter samples (`gather_samples`).
+
+Per-step semantics follow `SGMCMCSampler.sample_sgld` + `project_parameters`
+(sgmcmc_sampler.py:549-567, 650-656) with `noisy_gradient(kind='pf')` (:427-464); the RNG is
+the device Philox generator, so trajectories are statistically, not bitwise, equivalent to
+the reference (bitwise parity is what the REPLAY mode of the Sampler classes is for).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+from .sgmcmc_sampler import random_subsequence_and_weights
+
+_MODELS = {}
+
+
+def _model_info(model):
+    if not _MODELS:
+        from .models import svm, garch, lgssm
+        _MODELS.update(svm=(svm.SVMParameters, svm.SVMPrior, svm.SVMHelper),
+                       garch=(garch.GARCHParameters, garch.GARCHPrior, garch.GARCHHelper),
+                       lgssm=(lgssm.LGSSMParameters, lgssm.LGSSMPrior, lgssm.LGSSMHelper))
+    return _MODELS[model]
+
+
+def prior_hyper(model, prior):
+    """Flatten a (1-D) Prior's hyper-parameters into the pfg_prior_hyper struct."""
+    h = _capi.PriorHyper()
+    hp = prior.hyperparams
+    first = lambda v: float(np.asarray(v).reshape(-1)[0])
+    h.df_Rinv, h.scale_Rinv = first(hp['df_Rinv']), first(hp['scale_Rinv'])
+    h.df_Qinv = h.scale_Qinv = h.var_col_A = h.var_col_C = 1.0
+    if model in ("svm", "lgssm"):
+        h.df_Qinv, h.scale_Qinv = first(hp['df_Qinv']), first(hp['scale_Qinv'])
+        h.mean_A, h.var_col_A = first(hp['mean_A']), first(hp['var_col_A'])
+    if model == "lgssm":
+        h.mean_C, h.var_col_C = first(hp['mean_C']), first(hp['var_col_C'])
+    if model == "garch":
+        for k in ('scale_mu', 'shape_mu', 'alpha_phi', 'beta_phi', 'alpha_lambduh', 'beta_lambduh'):
+            setattr(h, k, first(hp[k]))
+    return h
+
+
+class ChainEnsemble(object):
+    """C independent SGLD chains of one model on one series, resident on `device`.
+
+    Args:
+      model: 'svm' | 'garch' | 'lgssm';  observations: (T,) or (T,1)
+      parameters: a Parameters object (all chains start there) or an array [C, P] of raw thetas
+      num_chains: C (ignored when `parameters` is an array)
+      N, pf ('poyiadjis_N' | 'nemeth'), lambduh, kernel: particle-filter settings
+      epsilon: SGLD step size;  prior: Prior (default: the model's default prior, var=100 / 1)
+      subsequence_length S / buffer_length B: -1 = full sequence (no window sampling)
+      dtype: 'f64' | 'f32' particle-state arithmetic;  seed: Philox key
+      chain_offset: global index of this rank's first chain (keeps streams distinct across GPUs)
+    """
+
+    def __init__(self, model, observations, parameters, num_chains=None, N=1000, pf="poyiadjis_N",
+                 lambduh=None, kernel=None, epsilon=0.1, prior=None, subsequence_length=-1,
+                 buffer_length=-1, dtype="f64", seed=0, chain_offset=0, device=None,
+                 forward_message=None, partition_style=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ChainEnsemble needs an MI355X (no CPU fallback)")
+        Parameters, Prior, Helper = _model_info(model)
+        self.model, self.N, self.dtype, self.epsilon = model, int(N), dtype, float(epsilon)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.ctx = _capi.default_context(self.device.index)
+        self.helper = Helper(n=1, m=1, forward_message=forward_message)
+        self.kernel = self.helper._get_kernel(kernel)
+        if pf == "poyiadjis_N":
+            self.lambduh = 1.0
+        elif pf == "nemeth":
+            self.lambduh = 0.95 if lambduh is None else float(lambduh)
+        else:
+            raise ValueError("ChainEnsemble supports pf = 'poyiadjis_N' | 'nemeth', got {0}".format(pf))
+        self.P = _capi.THETA_DIM[model]
+        self._Parameters = Parameters
+
+        y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
+        self.T = y.shape[0]
+        if isinstance(parameters, np.ndarray):
+            theta0 = np.ascontiguousarray(parameters, dtype=np.float64).reshape(-1, self.P)
+            proto = None
+        else:
+            if num_chains is None:
+                raise ValueError("num_chains is required when `parameters` is a Parameters object")
+            theta0 = np.tile(parameters.theta(), (int(num_chains), 1))
+            proto = parameters
+        self.C = theta0.shape[0]
+        if prior is None:
+            prior = Prior.generate_default_prior(var=1.0 if model == "garch" else 100.0, n=1, m=1)
+        self.prior = prior
+        self.hyper = prior_hyper(model, prior)
+        self.seed, self.chain_offset = int(seed), int(chain_offset)
+
+        S, B = int(subsequence_length), int(buffer_length)
+        if S == -1 or self.T - S <= 0:
+            S = -1
+        self.S, self.B = S, (self.T if B == -1 else B)
+        self.partition_style = partition_style
+
+        dev = self.device
+        th = np.zeros((self.C, _capi.MAX_THETA))
+        th[:, :self.P] = theta0
+        self.y_dev = torch.from_numpy(y).to(dev)
+        self.theta_dev = torch.from_numpy(th).to(dev)
+        self.out_dev = torch.zeros((self.C, _capi.OUT_DOUBLES), dtype=torch.float64, device=dev)
+        self.step_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.weights_dev = None
+        self._weights_table = None
+        if S > 0:
+            # importance weights depend on the window start only: one resident row per start
+            table = np.zeros((self.T - S + 1, S))
+            for start in range(self.T - S + 1):
+                table[start] = self._weights_for(start)
+            self._weights_table = table
+            self.weights_dev = torch.from_numpy(table).to(dev)
+        pm, pv, _ = self._prior_x(proto, theta0[0])
+        self._desc = np.zeros(self.C, dtype=_capi.DEV_PROBLEM_DTYPE)
+        d = self._desc
+        d["theta"] = self.theta_dev.data_ptr() + np.arange(self.C, dtype=np.uint64) * (8 * _capi.MAX_THETA)
+        d["out"] = self.out_dev.data_ptr() + np.arange(self.C, dtype=np.uint64) * (8 * _capi.OUT_DOUBLES)
+        d["step_ctr"] = self.step_ctr.data_ptr()
+        d["prior_mean"], d["prior_var"], d["lambduh"] = pm, pv, self.lambduh
+        d["seed"] = np.uint64(self.seed & 0xFFFFFFFFFFFFFFFF)
+        d["stream"] = np.arange(self.C, dtype=np.uint64) + np.uint64(self.chain_offset)
+        d["N"] = self.N
+        d["smoother"], d["stat"] = _capi.SMOOTHER["nemeth"], _capi.STAT["score"]
+        if model == "garch" and self.helper.default_forward_message is None:
+            d["flags"] = _capi.FLAG_GARCH_STATIONARY_PRIOR
+        self._host_rng = np.random.RandomState((self.seed * 7919 + self.chain_offset) % (2 ** 32))
+        self._set_windows(first=True)
+        self.desc_dev = torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)).to(dev)
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------------------------
+    def _weights_for(self, start):
+        """weights of random_subsequence_and_weights for a given start ('uniform' style)."""
+        S, T = self.S, self.T
+        style = self.partition_style or 'uniform'
+        if style in ('strict', 'naive'):
+            return np.ones(S) * T / S
+        t = np.arange(start, start + S)
+        cap = np.ones_like(t) * min(S, T - S + 1)
+        if start + S <= 2 * S:
+            covering = np.min(np.array([t + 1, cap]), axis=0)
+        elif start >= T - 2 * S - 1:
+            covering = np.min(np.array([T - t, cap]), axis=0)
+        else:
+            covering = np.ones(S) * S
+        return np.ones(S, dtype=float) * (T - S + 1) / covering
+
+    def _prior_x(self, proto, theta_row):
+        if proto is None:
+            proto = self._params_from_theta(theta_row)
+        return self.helper._prior_x(None, proto)
+
+    def _params_from_theta(self, th):
+        if self.model == "svm":
+            return self._Parameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+        if self.model == "lgssm":
+            return self._Parameters(A=np.eye(1) * th[0], C=np.eye(1) * th[1], LQinv=np.eye(1) * th[2],
+                                    LRinv=np.eye(1) * th[3])
+        return self._Parameters(log_mu=th[0], logit_phi=th[1], logit_lambduh=th[2], LRinv=np.eye(1) * th[3])
+
+    def _set_windows(self, first=False):
+        """Full sequence: static descriptors.  Buffered windows: draw one start per chain on the
+        host (sgmcmc_sampler.py:259-288) and point y / weights / t1 / tL at it."""
+        d = self._desc
+        if self.S == -1:
+            if first:
+                d["y"] = self.y_dev.data_ptr()
+                d["T"], d["t1"], d["tL"] = self.T, 0, self.T
+                d["weights"] = 0
+            return False
+        S, B, T = self.S, self.B, self.T
+        if (self.partition_style or 'uniform') == 'strict':
+            start = self._host_rng.randint(0, T // S, size=self.C) * S
+        else:
+            start = self._host_rng.randint(0, T - S + 1, size=self.C)
+        left = np.maximum(0, start - B)
+        right = np.minimum(T, start + S + B)
+        d["y"] = self.y_dev.data_ptr() + left.astype(np.uint64) * 8
+        d["T"] = right - left
+        d["t1"] = start - left
+        d["tL"] = start + S - left
+        d["weights"] = self.weights_dev.data_ptr() + start.astype(np.uint64) * (8 * S)
+        return True
+
+    # ------------------------------------------------------------------------------------
+    def launch_pf(self, stream=None):
+        """Enqueue one particle-filter launch for all chains on `stream` (default: torch's
+        current stream).  Results land in self.out_dev[C, 8] (score columns, loglik)."""
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self.ctx.launch_device(self.model, self.kernel, self.dtype, "philox", self.N, self.C,
+                               self.desc_dev.data_ptr(), st)
+
+    def launch_update(self, stream=None):
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self.ctx.sgld_update_device(self.model, self.C, self.theta_dev.data_ptr(), self.out_dev.data_ptr(),
+                                    self.hyper, self.epsilon, float(self.T), self.seed ^ 0x5DEECE66D,
+                                    self.step_ctr.data_ptr(), st)
+
+    def step(self, num_steps=1):
+        """num_steps x (sample_sgld + project_parameters) for every chain.  Asynchronous."""
+        for _ in range(num_steps):
+            if self.steps_done > 0 and self._set_windows():
+                self.desc_dev.copy_(torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)),
+                                    non_blocking=True)
+            self.launch_pf()
+            self.launch_update()
+            self.steps_done += 1
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------------------------
+    def theta(self):
+        """Current raw parameters of all chains, ndarray [C, P] (synchronises)."""
+        return self.theta_dev[:, :self.P].cpu().numpy()
+
+    def last_gradient_statistics(self):
+        """[C, h] score estimates and [C] log-likelihood estimates of the latest PF launch."""
+        out = self.out_dev.cpu().numpy()
+        return out[:, :_capi.STAT_DIM[self.model]], out[:, 4]
+
+    def parameters_list(self):
+        return [self._params_from_theta(th) for th in self.theta()]
+
+    def gather_samples(self):
+        """All ranks' current samples [world*C, P] on every rank, in global chain order: the one
+        collective of the multi-GPU path (RCCL all_gather over xGMI; a few KB, latency-bound)."""
+        from . import distributed
+        return distributed.gather_samples(self.theta_dev[:, :self.P].contiguous())

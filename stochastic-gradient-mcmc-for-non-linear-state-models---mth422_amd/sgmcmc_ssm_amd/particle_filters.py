@@ -1,0 +1,137 @@
+"""Buffered particle filter / smoother: Python face of the HIP kernels.
+
+`buffered_pf_wrapper` keeps the call shape of the reference function of the same name
+(particle_filters/buffered_smoother.py:156-199) but takes enumerated model / kernel /
+statistic ids instead of Python callables (callables cannot cross to the device), and runs
+the whole T-loop (:93-133) as ONE kernel launch in libpfgrad.so.
+
+RNG modes
+  rng='replay' (default): the N + 2*T*N draws the reference's loop would take from the global
+      legacy `np.random` state are drawn here, in the same order (N normals for x0, then per
+      timestep N uniforms for np.random.choice and N normals for Kernel.rv), and handed to the
+      kernel.  Results then reproduce the reference on identical seeds (fp64).
+  rng='philox': counter-based generator on the device (no host stream, no H2D traffic); the
+      fast path, statistically equivalent, not seed-compatible with the reference.
+
+There is no NumPy fallback: without libpfgrad.so and an MI355X every entry point raises.
+"""
+import numpy as np
+
+from . import _capi
+
+PF_NAMES = ("nemeth", "poyiadjis_N", "filter")
+NOT_ON_DEVICE = ("poyiadjis_N2", "paris")      # SURVEY.md 8(f) "next" rows
+
+
+def _smoother_of(pf, kwargs):
+    """pf name -> (smoother id, lambduh), as buffered_smoother.py:170-197 dispatches."""
+    if pf == "nemeth":
+        return "nemeth", float(kwargs.pop("lambduh", 0.95))
+    if pf == "poyiadjis_N":
+        kwargs.pop("lambduh", None)
+        return "nemeth", 1.0
+    if pf == "filter":
+        kwargs.pop("lambduh", None)
+        return "filter", 1.0
+    if pf in NOT_ON_DEVICE:
+        raise NotImplementedError(
+            "pf = '{0}' is not implemented on the HIP backend yet (O(N^2) / PaRIS smoothers)".format(pf))
+    raise ValueError("Unrecognized pf = {0}".format(pf))
+
+
+def draw_replay_streams(N, T, random_state=None):
+    """Take from `random_state` (default: the global legacy np.random) exactly what one
+    reference PF run takes, in its order.  Returns z0 (N,), u (T,N), z (T,N)."""
+    rs = np.random if random_state is None else random_state
+    z0 = rs.normal(size=N)
+    u = np.empty((T, N))
+    z = np.empty((T, N))
+    for t in range(T):
+        u[t] = rs.random_sample(N)
+        z[t] = rs.normal(size=N)
+    return z0, u, z
+
+
+_philox_calls = [0]
+
+
+def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weights=None,
+                 prior_mean=0.0, prior_var=1.0, stat="score", dtype="f64", rng="replay",
+                 seed=None, stream=None, flags=0, random_state=None, **kwargs):
+    """Build one problem dict for _capi.Context.run_batch."""
+    kwargs = dict(kwargs)
+    kwargs.pop("tqdm", None)
+    kwargs.pop("tqdm_name", None)
+    smoother, lambduh = _smoother_of(pf, kwargs)
+    y = np.ascontiguousarray(observations, dtype=float)
+    if y.ndim == 2:
+        if y.shape[1] != 1:
+            raise ValueError("the HIP particle filter supports m = 1 observations only")
+        y = y[:, 0]
+    T = y.shape[0]
+    q = dict(model=model, kernel=kernel, smoother=smoother, stat=stat, dtype=dtype, rng=rng,
+             N=int(N), t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=lambduh,
+             prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
+             prior_var=float(np.asarray(prior_var).reshape(-1)[0]),
+             y=y, weights=weights, theta=theta, flags=flags)
+    if rng == "replay":
+        q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state)
+    elif rng == "philox":
+        if seed is None:
+            # derive the device key from the host stream so np.random.seed() still controls runs
+            rs = np.random if random_state is None else random_state
+            seed = int(rs.randint(0, 2 ** 31 - 1)) | (int(rs.randint(0, 2 ** 31 - 1)) << 31)
+        if stream is None:
+            _philox_calls[0] += 1
+            stream = _philox_calls[0]
+        q["seed"], q["stream"] = int(seed), int(stream)
+    else:
+        raise ValueError("Unrecognized rng = {0}".format(rng))
+    return q
+
+
+def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
+                        save_all=False, want_final=True, **kwargs):
+    """Run one buffered PF window on the GPU.
+
+    Returns the reference's dict: x_t (N,n), log_weights (N,), statistics ((N,h), or (h,) for
+    pf='filter'), loglikelihood_estimate, plus mean_statistic (= average_statistic(out)) and,
+    with save_all=True, the all_* traces of buffered_smoother.py:128-142."""
+    q = make_problem(model, kernel, pf, observations, theta, N, **kwargs)
+    ctx = ctx or _capi.default_context()
+    o = ctx.run_batch([q], want_final=want_final or save_all, want_trace=save_all)[0]
+    return _to_reference_dict(o, q)
+
+
+def _to_reference_dict(o, q):
+    out = dict(loglikelihood_estimate=o["loglik"])
+    if q["smoother"] == "filter":
+        out["statistics"] = o["mean_stat"]
+    else:
+        out["mean_statistic"] = o["mean_stat"]
+        if "statistics" in o:
+            out["statistics"] = o["statistics"]
+    for src, dst in (("x_t", "x_t"), ("log_weights", "log_weights"), ("all_x_t", "all_x_t"),
+                     ("all_log_weights", "all_log_weights"), ("all_statistics", "all_statistics"),
+                     ("all_loglikelihood_estimate", "all_loglikelihood_estimate")):
+        if src in o:
+            out[dst] = o[src]
+    return out
+
+
+def run_windows(problems, ctx=None, want_final=False):
+    """Many independent windows (same model/kernel/dtype/rng) in ONE launch, one workgroup each."""
+    ctx = ctx or _capi.default_context()
+    outs = ctx.run_batch(problems, want_final=want_final)
+    return [_to_reference_dict(o, q) for o, q in zip(outs, problems)]
+
+
+def average_statistic(out):
+    """sum_i statistics_i * softmax(log_weights)_i  (buffered_smoother.py:151-154); the kernel
+    already returns it as out['mean_statistic']."""
+    if "mean_statistic" in out:
+        return out["mean_statistic"]
+    lw = out["log_weights"]
+    p = np.exp(lw - np.max(lw))
+    p /= np.sum(p)
+    return np.sum(out["statistics"].T * p, axis=1)

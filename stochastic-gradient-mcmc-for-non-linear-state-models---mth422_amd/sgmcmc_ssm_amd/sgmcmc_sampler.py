@@ -1,0 +1,560 @@
+"""SG-MCMC samplers whose noisy gradient comes from the HIP particle filter.
+
+Host-side orchestration of the reference's `sgmcmc_ssm/sgmcmc_sampler.py` for `kind='pf'`:
+window sampling, importance weights, prior gradient, 1/T scaling, the SGD / ADAGRAD / SGLD
+parameter updates and the fit loops.  All of it costs O(#parameters) per step and stays in
+Python; everything O(N*T) runs in libpfgrad.so.
+
+Every window a gradient needs (minibatch_size windows x num_sequences sequences) is collected
+first -- drawing from `np.random` in exactly the reference's order -- and then issued as ONE
+kernel launch with one workgroup per window.
+
+Behaviour kept from the reference on purpose (SURVEY.md 8b "quirks"):
+  * kind='pf' always differentiates at `self.parameters`, even if `parameters=` is passed
+    (sgmcmc_sampler.py:379).
+  * SGLD noise is drawn after the particle filter has consumed its draws, one
+    np.random.normal call per variable in `parameters.as_dict()` order (:540-546).
+Consciously changed: NaN / blow-up checks look at every gradient entry, not only the last
+dict key (:420-424 leaks the loop variable).
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import _capi
+from . import particle_filters as _pf
+
+logger = logging.getLogger(name=__name__)
+NOISE_NUGGET = 1e-9
+
+_ONLY_PF = ("only kind='pf' is implemented by the MI355X backend; kind='{0}' (analytic / "
+            "complete-data paths of the reference) is out of scope (SURVEY.md section 8)")
+
+
+# ----------------------------------------------------------------------------------------
+# window sampling (sgmcmc_sampler.py:1969-2017)
+# ----------------------------------------------------------------------------------------
+def random_subsequence_and_weights(S, T, partition_style=None):
+    """Draw a length-S window of a length-T series and the importance weights that make the
+    windowed sum unbiased for the full sum.  Consumes one np.random integer draw.
+
+    'uniform' (default): start ~ U{0..T-S}; weight_t = (T-S+1) / #windows covering t.
+    'strict': T % S == 0, start in {0,S,2S,..}; weights T/S.   'naive': weights T/S.
+    Returns (start, end, weights[S])."""
+    style = 'uniform' if partition_style is None else partition_style
+    if style == 'strict':
+        if T % S != 0:
+            raise ValueError("S {0} does not evenly divide T {1}".format(S, T))
+        start = np.random.choice(np.arange(0, T // S)) * S
+        weights = np.ones(S, dtype=float) * T / S
+    elif style == 'uniform':
+        start = np.random.randint(0, T - S + 1)
+        t = np.arange(start, start + S)
+        cap = np.ones_like(t) * min(S, T - S + 1)
+        if start + S <= 2 * S:
+            covering = np.min(np.array([t + 1, cap]), axis=0)
+        elif start >= T - 2 * S - 1:
+            covering = np.min(np.array([T - t, cap]), axis=0)
+        else:
+            covering = np.ones(S) * S
+        weights = np.ones(S, dtype=float) * (T - S + 1) / covering
+    elif style == 'naive':
+        start = np.random.randint(0, T - S + 1)
+        weights = np.ones(S, dtype=float) * T / S
+    else:
+        raise ValueError("Unrecognized partition_style = '{0}'".format(style))
+    return int(start), int(start + S), weights
+
+
+# ----------------------------------------------------------------------------------------
+# Helper: per-model particle-filter estimators (the hot-path entry)
+# ----------------------------------------------------------------------------------------
+class PFHelper(object):
+    """Base of SVMHelper / GARCHHelper / LGSSMHelper: `pf_gradient_estimate` and
+    `pf_loglikelihood_estimate` with the reference's signatures
+    (models/svm/helper.py:67-185, models/garch/helper.py:59-170, models/lgssm/helper.py:1016-1143)."""
+    model = None                 # 'svm' | 'garch' | 'lgssm'
+    default_kernel = None
+    kernels = ()
+    score_names = ()             # dict keys of the gradient, in statistic-column order
+
+    def __init__(self, n=1, m=1, forward_message=None, backward_message=None, **kwargs):
+        if n != 1 or m != 1:
+            raise NotImplementedError("the MI355X particle-filter backend covers n = m = 1 models")
+        self.n, self.m = n, m
+        if forward_message is None:
+            forward_message = self._default_forward_message()
+        self.default_forward_message = forward_message
+        if backward_message is None:
+            backward_message = dict(log_constant=0.0, mean_precision=np.zeros(self.n),
+                                    precision=np.zeros((self.n, self.n)))
+        self.default_backward_message = backward_message
+
+    def _default_forward_message(self):
+        return dict(log_constant=0.0, mean_precision=np.zeros(self.n), precision=np.eye(self.n) / 10)
+
+    def _get_kernel(self, kernel):
+        if kernel is None:
+            kernel = self.default_kernel
+        if kernel not in ("prior", "optimal"):
+            raise ValueError("Unrecoginized kernel = {0}".format(kernel))
+        if kernel not in self.kernels:
+            raise NotImplementedError("{0} {1} kernel not analytic".format(self.model.upper(), kernel))
+        return kernel
+
+    def _prior_x(self, forward_message, parameters):
+        """Prior mean / variance of x_{-1} from a Gaussian message.  The reference computes
+        prior_mean = solve(prior_var, mean_precision) (svm/helper.py:99-104) -- only right
+        because mean_precision == 0 in practice; reproduced as is."""
+        if forward_message is None:
+            forward_message = self.default_forward_message
+        prior_var = np.linalg.inv(forward_message['precision'])
+        prior_mean = np.linalg.solve(prior_var, forward_message['mean_precision'])
+        return float(np.reshape(prior_mean, -1)[0]), float(prior_var[0, 0]), 0
+
+    def pf_problem(self, observations, parameters, subsequence_start=0, subsequence_end=None,
+                   weights=None, pf="poyiadjis_N", N=1000, kernel=None, forward_message=None,
+                   stat="score", **kwargs):
+        """One window as a libpfgrad problem (draws its replay streams now)."""
+        kernel = self._get_kernel(kernel)
+        prior_mean, prior_var, flags = self._prior_x(forward_message, parameters)
+        return _pf.make_problem(self.model, kernel, pf, observations, parameters.theta(), N,
+                                t1=subsequence_start, tL=subsequence_end, weights=weights,
+                                prior_mean=prior_mean, prior_var=prior_var, stat=stat, flags=flags,
+                                **kwargs)
+
+    def grad_from_statistic(self, mean_statistic):
+        return dict(zip(self.score_names, mean_statistic))
+
+    def pf_gradient_estimate(self, observations, parameters, subsequence_start=0,
+                             subsequence_end=None, weights=None, pf="poyiadjis_N", N=1000,
+                             kernel=None, forward_message=None, **kwargs):
+        """Particle-filter score estimate -> dict of gradients keyed like parameters.var_dict."""
+        q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
+                            pf, N, kernel, forward_message, stat="score", **kwargs)
+        if q["smoother"] == "filter":
+            raise ValueError("pf = 'filter' has no per-particle statistics to average "
+                             "(the reference fails in average_statistic for it)")
+        out = _pf.run_windows([q])[0]
+        return self.grad_from_statistic(out["mean_statistic"])
+
+    def pf_loglikelihood_estimate(self, observations, parameters, subsequence_start=0,
+                                  subsequence_end=None, weights=None, pf="poyiadjis_N", N=1000,
+                                  kernel=None, forward_message=None, **kwargs):
+        """Particle-filter marginal log-likelihood estimate (the sufficient statistics the
+        reference accumulates alongside are not returned by it either)."""
+        q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
+                            pf, N, kernel, forward_message, stat="suff", **kwargs)
+        return _pf.run_windows([q])[0]["loglikelihood_estimate"]
+
+
+# ----------------------------------------------------------------------------------------
+# Sampler
+# ----------------------------------------------------------------------------------------
+class SGMCMCSampler(object):
+    """Base class: SG-MCMC for one time series with particle-filter gradients."""
+
+    def __init__(self, **kwargs):
+        raise NotImplementedError()
+
+    # -- init ------------------------------------------------------------------------------
+    def prior_init(self):
+        self.parameters = self.prior.sample_prior()
+        return self.parameters
+
+    # -- observations ------------------------------------------------------------------------
+    @property
+    def observations(self):
+        return self._observations
+
+    @observations.setter
+    def observations(self, observations):
+        self._check_observation_shape(observations)
+        self._observations = observations
+
+    def _check_observation_shape(self, observations):
+        return
+
+    def _get_observations(self, observations, check_shape=True):
+        if observations is None:
+            observations = self.observations
+            if observations is None:
+                raise ValueError("observations not specified")
+        elif check_shape:
+            self._check_observation_shape(observations)
+        return observations
+
+    def _get_T(self, **kwargs):
+        T = kwargs.get('T')
+        if T is None:
+            observations = self._get_observations(kwargs.get('observations'))
+            T = observations.shape[0]
+        return T
+
+    # -- windows -------------------------------------------------------------------------------
+    def _random_subsequence_and_buffers(self, buffer_length, subsequence_length, T=None):
+        """Window [start,end) plus up to buffer_length extra points each side
+        (sgmcmc_sampler.py:259-288)."""
+        if T is None:
+            T = self._get_T()
+        if buffer_length == -1:
+            buffer_length = T
+        if (subsequence_length == -1) or (T - subsequence_length <= 0):
+            start, end, weights = 0, T, None
+        else:
+            start, end, weights = random_subsequence_and_weights(
+                S=subsequence_length, T=T, partition_style=self.options.get('partition_style'))
+        return dict(subsequence_start=start, subsequence_end=end,
+                    left_buffer_start=max(0, start - buffer_length),
+                    right_buffer_end=min(T, end + buffer_length), weights=weights)
+
+    def _window_problem(self, buffer_dict, observations, stat, **kwargs):
+        rel_start = buffer_dict['subsequence_start'] - buffer_dict['left_buffer_start']
+        rel_end = buffer_dict['subsequence_end'] - buffer_dict['left_buffer_start']
+        buffer_ = observations[buffer_dict['left_buffer_start']:buffer_dict['right_buffer_end']]
+        return self.message_helper.pf_problem(
+            observations=buffer_, parameters=self.parameters, subsequence_start=rel_start,
+            subsequence_end=rel_end, weights=buffer_dict['weights'], stat=stat, **kwargs)
+
+    @staticmethod
+    def _require_pf(kind):
+        if kind != 'pf':
+            raise NotImplementedError(_ONLY_PF.format(kind))
+
+    # -- log-likelihood --------------------------------------------------------------------------
+    def _loglike_problems(self, kind='pf', subsequence_length=-1, minibatch_size=1, buffer_length=10,
+                          num_samples=None, observations=None, parameters=None, check_shape=True,
+                          **kwargs):
+        self._require_pf(kind)
+        observations = self._get_observations(observations, check_shape=check_shape)
+        if kwargs.get("N", None) is None:
+            kwargs['N'] = num_samples if num_samples is not None else 1000
+        T = observations.shape[0]
+        probs = []
+        for _ in range(minibatch_size):
+            # the reference draws a window and runs its filter inside one loop body (:210-237)
+            bd = self._random_subsequence_and_buffers(buffer_length=buffer_length,
+                                                      subsequence_length=subsequence_length, T=T)
+            probs.append((self._window_problem(bd, observations, "suff", **kwargs), minibatch_size))
+        return probs
+
+    def noisy_loglikelihood(self, **kwargs):
+        """Subsequence approximation to the log-likelihood (kind='pf')."""
+        kwargs.pop('tqdm', None)
+        probs = self._loglike_problems(**kwargs)
+        outs = _pf.run_windows([q for q, _ in probs])
+        value = 0.0
+        for o in outs:
+            value += o["loglikelihood_estimate"]
+        value *= 1.0 / probs[0][1]
+        if np.isnan(value):
+            raise ValueError("NaNs in loglikelihood")
+        return value
+
+    def noisy_logjoint(self, return_loglike=False, **kwargs):
+        loglikelihood = self.noisy_loglikelihood(**kwargs)
+        logprior = self.prior.logprior(self.parameters)
+        if return_loglike:
+            return dict(logjoint=loglikelihood + logprior, loglikelihood=loglikelihood)
+        return loglikelihood + logprior
+
+    # -- gradient ------------------------------------------------------------------------------------
+    def _grad_problems(self, subsequence_length=-1, minibatch_size=1, buffer_length=0,
+                       observations=None, buffer_dicts=None, kind='pf', num_samples=None,
+                       parameters=None, **kwargs):
+        """All windows of one gradient for ONE series -> [(problem, minibatch_size)].  RNG order
+        as sgmcmc_sampler.py:390-418: every window is drawn first, then each filter's streams."""
+        self._require_pf(kind)
+        observations = self._get_observations(observations, check_shape=False)
+        if kwargs.get("N", None) is None:
+            kwargs['N'] = num_samples if num_samples is not None else 1000
+        T = observations.shape[0]
+        if buffer_dicts is None:
+            buffer_dicts = [self._random_subsequence_and_buffers(
+                buffer_length=buffer_length, subsequence_length=subsequence_length, T=T)
+                for _ in range(minibatch_size)]
+        elif len(buffer_dicts) != minibatch_size:
+            raise ValueError("len(buffer_dicts != minibatch_size")
+        return [(self._window_problem(bd, observations, "score", **kwargs), minibatch_size)
+                for bd in buffer_dicts]
+
+    def _run_grad_problems(self, groups):
+        """groups: list (one per series) of [(problem, minibatch_size)].  One launch for all
+        windows; sums in the reference's order (within a series, then across series)."""
+        names = self.message_helper.score_names
+        flat = [q for group in groups for q, _ in group]
+        for q in flat:
+            if q["smoother"] == "filter":
+                raise ValueError("pf = 'filter' cannot be used for gradients")
+        outs = iter(_pf.run_windows(flat))
+        grad = None
+        for group in groups:
+            part = {var: np.zeros_like(value) for var, value in self.parameters.as_dict().items()}
+            for _, minibatch_size in group:
+                o = next(outs)
+                for name, g in zip(names, o["mean_statistic"]):
+                    part[name] += g * 1.0 / minibatch_size
+            grad = part if grad is None else {var: grad[var] + part[var] for var in part}
+        for var in grad:
+            if np.any(np.isnan(grad[var])):
+                raise ValueError("NaNs in gradient of {0}".format(var))
+            if np.linalg.norm(grad[var]) > 1e16:
+                logger.warning("Norm of noisy_grad_loglike[{1} > 1e16: {0}".format(grad[var], var))
+        return grad
+
+    def _noisy_grad_loglikelihood(self, **kwargs):
+        return self._run_grad_problems([self._grad_problems(**kwargs)])
+
+    def noisy_gradient(self, preconditioner=None, is_scaled=True, **kwargs):
+        """grad log-likelihood (particle filter, buffered) + grad log-prior, optionally / T
+        (sgmcmc_sampler.py:427-464)."""
+        if preconditioner is not None:
+            raise NotImplementedError("preconditioned (SGRLD) steps are not on the PF path yet")
+        kwargs.pop('tqdm', None)
+        T_total = self._get_T(**kwargs)
+        grad_loglike = self._noisy_grad_loglikelihood(**{k: v for k, v in kwargs.items() if k != 'T'})
+        grad_prior = self.prior.grad_logprior(parameters=self.parameters)
+        grad = {var: grad_prior[var] + grad_loglike[var] for var in grad_prior}
+        if is_scaled:
+            for var in grad:
+                grad[var] = grad[var] / T_total
+        return grad
+
+    # -- steps ---------------------------------------------------------------------------------------
+    def step_sgd(self, epsilon, **kwargs):
+        delta = self.noisy_gradient(**kwargs)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += epsilon * delta[var]
+        return self.parameters
+
+    def step_adagrad(self, epsilon, **kwargs):
+        if not hasattr(self, "_adagrad_moments"):
+            self._adagrad_moments = dict(t=0, G=0.0)
+        g = self.parameters.from_dict_to_vector(self.noisy_gradient(**kwargs))
+        G = self._adagrad_moments['G'] + g ** 2
+        delta = self.parameters.from_vector_to_dict(g / np.sqrt(G + NOISE_NUGGET), **self.parameters.dim)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += epsilon * delta[var]
+        self._adagrad_moments['t'] += 1
+        self._adagrad_moments['G'] = G
+        return self.parameters
+
+    def _get_sgmcmc_noise(self, is_scaled=True, preconditioner=None, **kwargs):
+        scale = 1.0 / self._get_T(**kwargs) if is_scaled else 1.0
+        return {var: np.random.normal(loc=0, scale=np.sqrt(scale), size=value.shape)
+                for var, value in self.parameters.as_dict().items()}
+
+    def sample_sgld(self, epsilon, **kwargs):
+        """theta += eps * noisy_gradient + sqrt(2 eps) * N(0, 1/T)  (sgmcmc_sampler.py:549-567)."""
+        if "preconditioner" in kwargs:
+            raise ValueError("Use SGRLD instead")
+        delta = self.noisy_gradient(**kwargs)
+        white_noise = self._get_sgmcmc_noise(**kwargs)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += epsilon * delta[var] + np.sqrt(2.0 * epsilon) * white_noise[var]
+        return self.parameters
+
+    def sample_sgrld(self, epsilon, preconditioner, **kwargs):
+        raise NotImplementedError("SGRLD preconditioning is a 'next' row (SURVEY.md 8f)")
+
+    def sample_gibbs(self):
+        raise NotImplementedError()
+
+    def project_parameters(self, **kwargs):
+        self.parameters.project_parameters(**self.options, **kwargs)
+        return self.parameters
+
+    # -- fit loops -----------------------------------------------------------------------------------
+    def get_iter_step(self, iter_type, steps_per_iteration=1, **kwargs):
+        """(function names, kwargs) of one iteration, as sgmcmc_sampler.py:896-947."""
+        project_kwargs = kwargs.get("project_kwargs", {})
+        if iter_type == 'custom':
+            names, kws = kwargs.get("iter_func_names"), kwargs.get("iter_func_kwargs")
+        elif iter_type in ('SGD', 'ADAGRAD', 'SGLD'):
+            grad_kwargs = dict(epsilon=kwargs['epsilon'],
+                               subsequence_length=kwargs['subsequence_length'],
+                               buffer_length=kwargs['buffer_length'],
+                               minibatch_size=kwargs.get('minibatch_size', 1),
+                               kind=kwargs.get("kind", "pf"),
+                               num_samples=kwargs.get("num_samples", None),
+                               **kwargs.get("pf_kwargs", {}))
+            if 'num_sequences' in kwargs:
+                grad_kwargs['num_sequences'] = kwargs['num_sequences']
+            step = dict(SGD='step_sgd', ADAGRAD='step_adagrad', SGLD='sample_sgld')[iter_type]
+            names, kws = [step, 'project_parameters'], [grad_kwargs, project_kwargs]
+        elif iter_type in ('SGRD', 'SGRLD', 'Gibbs'):
+            raise NotImplementedError("iter_type '{0}' is not on the particle-filter path".format(iter_type))
+        else:
+            raise ValueError("Unrecognized iter_type {0}".format(iter_type))
+        return names * steps_per_iteration, kws * steps_per_iteration
+
+    def _run_iter(self, names, kws):
+        for name, kw in zip(names, kws):
+            getattr(self, name)(**kw)
+
+    def fit(self, iter_type, num_iters, output_all=False, observations=None, init_parameters=None,
+            tqdm=None, catch_interrupt=False, **kwargs):
+        """num_iters iterations; returns the final Parameters or, with output_all, the list of
+        num_iters + 1 Parameters (sgmcmc_sampler.py:659-721)."""
+        if observations is not None:
+            self.observations = observations
+        if init_parameters is not None:
+            self.parameters = init_parameters.copy()
+        names, kws = self.get_iter_step(iter_type, **kwargs)
+        history = [self.parameters.copy()] if output_all else None
+        steps = range(1, num_iters + 1)
+        if tqdm is not None:
+            steps = tqdm(steps)
+            steps.set_description("fit using {0} iters".format(iter_type))
+        for it in steps:
+            try:
+                self._run_iter(names, kws)
+                if output_all:
+                    history.append(self.parameters.copy())
+            except KeyboardInterrupt as e:
+                if not catch_interrupt:
+                    raise e
+                logger.warning("Interrupt in fit:\n{0}\nStopping early after {1} iters".format(e, it))
+                return history[:it] if output_all else self.parameters.copy()
+        return history if output_all else self.parameters.copy()
+
+    def fit_evaluate(self, iter_type, metric_functions=None, max_num_iters=None, max_time=60,
+                     min_save_time=1, observations=None, init_parameters=None, tqdm=None,
+                     tqdm_iter=False, catch_interrupt=False, total_max_time=None, **kwargs):
+        """Time-budgeted fit: keep stepping, save a copy of the parameters at most every
+        min_save_time seconds until max_time seconds of sampler time are used
+        (sgmcmc_sampler.py:762-894).  Returns three pandas DataFrames
+        (parameters_list[iteration, parameters], times[iteration, time], metrics[...]).
+        metric_functions: callables f(sampler) -> dict | list of dict(metric, variable, value)."""
+        import pandas as pd
+        if observations is not None:
+            self.observations = observations
+        if init_parameters is not None:
+            self.parameters = init_parameters.copy()
+        if metric_functions is None:
+            metric_functions = []
+        elif callable(metric_functions):
+            metric_functions = [metric_functions]
+        names, kws = self.get_iter_step(iter_type, **kwargs)
+        num_saves = int(max_time // min_save_time)
+        if max_num_iters is not None:
+            num_saves = min(num_saves, max_num_iters)
+
+        rows = []
+
+        def evaluate(iteration):
+            for f in metric_functions:
+                res = f(self)
+                for r in ([res] if isinstance(res, dict) else res):
+                    rows.append(dict(iteration=iteration, metric=r['metric'], variable=r['variable'],
+                                     value=r['value']))
+
+        saved, times, iterations = [self.parameters.copy()], [0.0], [0]
+        evaluate(0)
+        iteration, total_time = 0, 0.0
+        start, last_save = time.time(), time.time()
+        saves = range(1, num_saves + 1)
+        if tqdm is not None:
+            saves = tqdm(saves)
+        try:
+            for _ in saves:
+                for step in range(1000):
+                    self._run_iter(names, kws)
+                    if time.time() - last_save > min_save_time:
+                        total_time += time.time() - last_save
+                        iteration += step + 1
+                        saved.append(self.parameters.copy())
+                        times.append(total_time)
+                        iterations.append(iteration)
+                        evaluate(iteration)
+                        last_save = time.time()
+                        break
+                if total_time > max_time:
+                    break
+                if total_max_time is not None and time.time() - start > total_max_time:
+                    break
+        except KeyboardInterrupt as e:
+            if not catch_interrupt:
+                raise e
+            logger.warning("Interrupt in fit_timed:\n{0}\nStopping early".format(e))
+        parameters_list = pd.DataFrame(dict(iteration=iterations, parameters=saved))
+        times_df = pd.DataFrame(dict(iteration=iterations, time=times))
+        metrics = pd.DataFrame(rows, columns=['iteration', 'metric', 'variable', 'value'])
+        return parameters_list, times_df, metrics
+
+    def fit_timed(self, iter_type, max_time=60, min_save_time=1, observations=None,
+                  init_parameters=None, tqdm=None, tqdm_iter=False, catch_interrupt=False, **kwargs):
+        """-> (list of Parameters, list of cumulative fit times)  (sgmcmc_sampler.py:723-760)."""
+        plist, times, _ = self.fit_evaluate(
+            iter_type=iter_type, max_time=max_time, min_save_time=min_save_time,
+            observations=observations, init_parameters=init_parameters, tqdm=tqdm,
+            tqdm_iter=tqdm_iter, catch_interrupt=catch_interrupt, **kwargs)
+        return plist['parameters'].tolist(), times['time'].tolist()
+
+    # -- out of scope on this backend -------------------------------------------------------------------
+    def predict(self, *args, **kwargs):
+        raise NotImplementedError("predict / pf_latent_var_distr is a 'next' row (SURVEY.md 8f)")
+
+    def exact_loglikelihood(self, *args, **kwargs):
+        raise NotImplementedError(_ONLY_PF.format('marginal'))
+
+
+class SeqSGMCMCSampler(object):
+    """Mixin: `observations` is a list of independent sequences (sgmcmc_sampler.py:1157-1283).
+    All windows of all chosen sequences go to the GPU in one launch."""
+
+    def _get_T(self, **kwargs):
+        T = kwargs.get('T')
+        if T is None:
+            observations = self._get_observations(kwargs.get('observations'))
+            T = int(np.sum([np.shape(observation)[0] for observation in observations]))
+        return T
+
+    def _check_observation_shape(self, observations):
+        if observations is not None:
+            for ii, observation in enumerate(observations):
+                try:
+                    super()._check_observation_shape(observations=observation)
+                except ValueError as e:
+                    raise ValueError("Error in observations[{0}] :\n{1}".format(ii, e))
+
+    def _choose_sequences(self, observations, num_sequences):
+        indices = np.arange(len(observations))
+        if num_sequences != -1:
+            indices = np.random.choice(indices, num_sequences, replace=False)
+        return indices
+
+    def noisy_loglikelihood(self, num_sequences=-1, observations=None, tqdm=None, **kwargs):
+        observations = self._get_observations(observations)
+        kwargs.pop('check_shape', None)
+        groups, S = [], 0.0
+        for index in self._choose_sequences(observations, num_sequences):
+            S += observations[index].shape[0]
+            # check_shape=False: the reference re-checks ONE sequence as if it were a list of
+            # sequences here, which raises IndexError for LGSSM (lgssm/sampler.py:61); fixed.
+            groups.append(SGMCMCSampler._loglike_problems(
+                self, observations=observations[index], check_shape=False, **kwargs))
+        outs = iter(_pf.run_windows([q for group in groups for q, _ in group]))
+        value = 0.0
+        for group in groups:
+            part = 0.0
+            for _ in group:
+                part += next(outs)["loglikelihood_estimate"]
+            value += part * (1.0 / group[0][1])
+        if np.isnan(value):
+            raise ValueError("NaNs in loglikelihood")
+        if num_sequences != -1:
+            value *= self._get_T(**kwargs) / S
+        return value
+
+    def _noisy_grad_loglikelihood(self, num_sequences=-1, **kwargs):
+        observations = self.observations
+        groups, S = [], 0.0
+        for index in self._choose_sequences(observations, num_sequences):
+            groups.append(SGMCMCSampler._grad_problems(self, observations=observations[index], **kwargs))
+            S += observations[index].shape[0]
+        grad = self._run_grad_problems(groups)
+        if num_sequences != -1:
+            grad = {var: grad[var] * self._get_T(**kwargs) / S for var in grad}
+        return grad

@@ -1,0 +1,21 @@
+"""Test-only adapter: evaluate libpfgrad problem dicts with the CPU oracle.
+
+Used by the CPU (`-m "not gpu"`) tests to exercise the *host* logic of the samplers (window
+sampling, RNG order, prior gradients, updates, projections) against the reference's golden
+trajectories without a GPU, by monkeypatching `sgmcmc_ssm_amd.particle_filters.run_windows`.
+The product never imports this."""
+from oracle import pf_oracle as po
+
+
+def run_windows_oracle(problems, ctx=None, want_final=False):
+    outs = []
+    for q in problems:
+        if q["rng"] != "replay":
+            raise ValueError("the oracle can only replay host streams")
+        pf = "filter" if q["smoother"] == "filter" else "nemeth"
+        r = po.pf_window(q["model"], q["theta"], q["y"], q["N"], q["z0"], q["u"], q["z"],
+                         kernel=q["kernel"], pf=pf, lambduh=q["lambduh"], stat=q["stat"],
+                         t1=q["t1"], tL=q["tL"], weights=q["weights"],
+                         prior_mean=q["prior_mean"], prior_var=q["prior_var"])
+        outs.append(r)
+    return outs

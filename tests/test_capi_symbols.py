@@ -1,0 +1,53 @@
+"""The C-ABI library builds, loads and exports every function include/pfgrad.h declares.
+No compute calls here (no GPU in the CPU suite)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from sgmcmc_ssm_amd import _capi, _build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "pfgrad.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|int64_t|char)\s*\*?\s*(pfg_\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    assert set(names) == set(_capi.EXPORTS), (names, _capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    if _build.is_stale():
+        _build.build_library()
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_binding_struct_sizes_and_version():
+    lib = _capi.load_library()          # asserts the struct sizes against pfg_struct_size()
+    assert lib.pfg_version() == 100
+    assert lib.pfg_struct_size(2) == _capi.DEV_PROBLEM_DTYPE.itemsize == 224
+    assert lib.pfg_struct_size(99) == -1
+    assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4"
+    assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
+    assert lib.pfg_variant_name(0, 0, 0, 1, 4000) == b"wg1024x4"
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product path must fail loudly, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_capi.PfgError, match="no HIP device|no CPU fallback"):
+        _capi.Context(0)
+    assert "oracle" not in " ".join(open(os.path.join(os.path.dirname(_capi.__file__), f)).read()
+                                    for f in os.listdir(os.path.dirname(_capi.__file__)) if f.endswith(".py")
+                                    ).replace("oracle fixtures", "")

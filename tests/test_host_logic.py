@@ -1,0 +1,244 @@
+"""Host-side logic (CPU): Parameters / Prior / projection / window weights / data generators
+and the sampler orchestration, against fixtures produced by the reference."""
+import numpy as np
+import pytest
+
+from sgmcmc_ssm_amd.models.svm import (SVMParameters, SVMPrior, SVMSampler, SeqSVMSampler,
+                                       generate_svm_data)
+from sgmcmc_ssm_amd.models.garch import (GARCHParameters, GARCHPrior, GARCHSampler, SeqGARCHSampler,
+                                         generate_garch_data)
+from sgmcmc_ssm_amd.models.lgssm import (LGSSMParameters, LGSSMPrior, LGSSMSampler, SeqLGSSMSampler,
+                                         generate_lgssm_data)
+from sgmcmc_ssm_amd import sgmcmc_sampler, particle_filters
+from oracle_backend import run_windows_oracle
+
+PARAMS = {"svm": SVMParameters, "garch": GARCHParameters, "lgssm": LGSSMParameters}
+PRIORS = {"svm": SVMPrior, "garch": GARCHPrior, "lgssm": LGSSMPrior}
+SAMPLERS = {"svm": (SVMSampler, SeqSVMSampler), "garch": (GARCHSampler, SeqGARCHSampler),
+            "lgssm": (LGSSMSampler, SeqLGSSMSampler)}
+GEN = {"svm": generate_svm_data, "garch": generate_garch_data, "lgssm": generate_lgssm_data}
+DATA_SEED = {"svm": 12345, "garch": 222, "lgssm": 333}
+
+
+def from_theta(model, th):
+    if model == "svm":
+        return SVMParameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+    if model == "lgssm":
+        return LGSSMParameters(A=np.eye(1) * th[0], C=np.eye(1) * th[1], LQinv=np.eye(1) * th[2],
+                               LRinv=np.eye(1) * th[3])
+    return GARCHParameters(log_mu=th[0], logit_phi=th[1], logit_lambduh=th[2], LRinv=np.eye(1) * th[3])
+
+
+def vec(model, d):
+    names = {"svm": ("A", "LQinv_vec", "LRinv_vec"), "lgssm": ("A", "C", "LQinv_vec", "LRinv_vec"),
+             "garch": ("log_mu", "logit_phi", "logit_lambduh", "LRinv_vec")}[model]
+    return np.array([float(np.asarray(d[k]).reshape(-1)[0]) for k in names])
+
+
+def default_params(model):
+    if model == "svm":
+        return SVMParameters(A=np.eye(1) * 0.95, Q=np.eye(1) * 0.5, R=np.eye(1) * 0.5)
+    if model == "lgssm":
+        return LGSSMParameters(A=np.eye(1) * 0.9, C=np.eye(1) * 1.0, Q=np.eye(1) * 0.7, R=np.eye(1) * 1.0)
+    lm, lp, ll = GARCHParameters.convert_alpha_beta_gamma(0.1, 0.8, 0.05)
+    return GARCHParameters(log_mu=lm, logit_phi=lp, logit_lambduh=ll, LRinv=np.eye(1) * 0.3 ** -0.5)
+
+
+# ---------------------------------------------------------------------------------------
+def test_parameters_interface():
+    p = default_params("svm")
+    assert list(p.var_dict) == ["A", "LQinv_vec", "LRinv_vec"]
+    assert p.dim == {"n": 1, "m": 1} and p.n == 1 and p.m == 1
+    assert p.A.shape == (1, 1) and p.LQinv_vec.shape == (1,) and p.LQinv.shape == (1, 1)
+    np.testing.assert_allclose(p.Q, [[0.5]], rtol=1e-15)
+    np.testing.assert_allclose(p.Qinv, p.LQinv ** 2 + 1e-16)
+    assert p.phi is p.var_dict["A"]
+    q = p.copy()
+    q.var_dict["A"] += 1.0
+    assert p.A[0, 0] == 0.95
+    v = p.as_vector()
+    assert v.shape == (3,)
+    d = SVMParameters.from_vector_to_dict(v, **p.dim)
+    assert d["A"].shape == (1, 1) and d["LRinv_vec"].shape == (1,)
+    r = p + {k: np.ones_like(x) for k, x in p.var_dict.items()}
+    assert r.A[0, 0] == 1.95
+    assert list(default_params("lgssm").var_dict) == ["A", "C", "LQinv_vec", "LRinv_vec"]
+    g = default_params("garch")
+    assert list(g.var_dict) == ["log_mu", "logit_phi", "logit_lambduh", "LRinv_vec"]
+    np.testing.assert_allclose([g.alpha[0], g.beta[0], g.gamma[0]], [0.1, 0.8, 0.05], rtol=1e-12)
+    np.testing.assert_allclose(g.theta(), [g.log_mu[0], g.logit_phi[0], g.logit_lambduh[0], g.LRinv[0, 0]])
+    with pytest.raises(ValueError):
+        SVMParameters(A=np.eye(1), LQinv=np.eye(1))
+
+
+def test_theta_matches_golden(golden_sampler):
+    for model in PARAMS:
+        np.testing.assert_array_equal(default_params(model).theta(), golden_sampler[model + "/theta0"])
+
+
+def test_data_generators_reproduce_reference(golden_sampler):
+    for model in PARAMS:
+        np.random.seed(DATA_SEED[model])
+        data = GEN[model](T=200, parameters=default_params(model))
+        assert data["observations"].shape == (200, 1)
+        np.testing.assert_array_equal(data["observations"].reshape(-1), golden_sampler[model + "/y"])
+
+
+def test_random_subsequence_and_weights(golden_host):
+    for m in golden_host.meta["subseq"]:
+        np.random.seed(m["seed"])
+        s, e, w = sgmcmc_sampler.random_subsequence_and_weights(S=m["S"], T=m["T"])
+        assert (s, e) == (m["start"], m["end"])
+        np.testing.assert_array_equal(w, golden_host.get(m["key"], "weights"))
+    np.random.seed(0)
+    assert sgmcmc_sampler.random_subsequence_and_weights(S=16, T=300)[:2] == (172, 188)
+    with pytest.raises(ValueError):
+        sgmcmc_sampler.random_subsequence_and_weights(S=7, T=20, partition_style="strict")
+
+
+def test_prior_grad_and_logprior(golden_host):
+    for m in golden_host.meta["prior"]:
+        model = m["model"]
+        prior = PRIORS[model].generate_default_prior(var=m["var"], n=1, m=1)
+        p = from_theta(model, golden_host.get(m["key"], "theta"))
+        g = prior.grad_logprior(p)
+        np.testing.assert_array_equal(vec(model, g), golden_host.get(m["key"], "grad"))
+        assert prior.logprior(p) == float(golden_host.get(m["key"], "logprior"))
+
+
+def test_project_parameters(golden_host):
+    for m in golden_host.meta["project"]:
+        p = from_theta(m["model"], golden_host.get(m["key"], "before"))
+        out = p.project_parameters()
+        assert out is p
+        np.testing.assert_array_equal(p.theta(), golden_host.get(m["key"], "after"))
+    p = default_params("svm")
+    p.project_parameters(A=dict(fixed=np.eye(1) * 0.3), Q=dict(thresh=False))
+    assert p.A[0, 0] == 0.3
+
+
+def test_prior_sampling_runs():
+    np.random.seed(1)
+    for model in PARAMS:
+        prior = PRIORS[model].generate_default_prior(var=1.0, n=1, m=1)
+        p = prior.sample_prior()
+        assert isinstance(p, PARAMS[model]) and np.all(np.isfinite(p.theta()))
+        q = PRIORS[model].generate_prior(p, from_mean=True, var=2.0)
+        assert np.all(np.isfinite(vec(model, q.grad_logprior(p))))
+
+
+# ---------------------------------------------------------------------------------------
+# sampler orchestration: oracle stands in for the GPU (monkeypatched), trajectories must be
+# IDENTICAL to the reference's (same RNG order, same arithmetic on the host side)
+# ---------------------------------------------------------------------------------------
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    monkeypatch.setattr(particle_filters, "run_windows", run_windows_oracle)
+
+
+def _check_sampler_case(g, meta, exact=True, rtol=0.0):
+    model, key = meta["model"], meta["key"]
+    Sampler = SAMPLERS[model][0]
+    y = g[model + "/y"].reshape(-1, 1)
+    kwargs = dict(kind="pf", pf=meta["pf"], N=meta["N"], subsequence_length=meta["S"],
+                  buffer_length=meta["B"], minibatch_size=1)
+    cmp = (np.testing.assert_array_equal if exact else
+           (lambda a, b: np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol)))
+    sampler = Sampler(n=1, m=1, observations=y, parameters=default_params(model))
+    np.random.seed(meta["seed"])
+    cmp(vec(model, sampler.noisy_gradient(**kwargs)), g.get(key, "noisy_gradient"))
+    np.random.seed(meta["seed"])
+    cmp(vec(model, sampler.noisy_gradient(is_scaled=False, **kwargs)), g.get(key, "noisy_gradient_unscaled"))
+    np.random.seed(meta["seed"])
+    cmp(np.float64(sampler.noisy_loglikelihood(**kwargs)), g.get(key, "noisy_loglikelihood"))
+    np.random.seed(meta["seed"] + 1)
+    traj = [sampler.parameters.theta()]
+    for _ in range(meta["nsteps"]):
+        sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+        traj.append(sampler.parameters.theta())
+        sampler.project_parameters()
+        traj.append(sampler.parameters.theta())
+    cmp(np.array(traj), g.get(key, "sgld_traj"))
+    for it in ("SGD", "ADAGRAD", "SGLD"):
+        sampler = Sampler(n=1, m=1, observations=y, parameters=default_params(model))
+        np.random.seed(meta["seed"] + 2)
+        plist = sampler.fit(iter_type=it, num_iters=3, output_all=True, epsilon=meta["eps"] * 0.1,
+                            subsequence_length=meta["S"], buffer_length=meta["B"], kind="pf",
+                            pf_kwargs=dict(pf=meta["pf"], N=meta["N"]))
+        assert len(plist) == 4
+        cmp(np.array([q.theta() for q in plist]), g.get(key, "fit_" + it))
+
+
+def test_sampler_trajectories_match_reference(oracle_backend, golden_sampler):
+    assert len(golden_sampler.meta) == 12
+    for meta in golden_sampler.meta:
+        _check_sampler_case(golden_sampler, meta, exact=True)
+
+
+def _check_seq_and_minibatch(g, model, exact=True, rtol=0.0):
+    Sampler, SeqSampler = SAMPLERS[model]
+    cmp = (np.testing.assert_array_equal if exact else
+           (lambda a, b: np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol)))
+    y = g[model + "/y"].reshape(-1, 1)
+    eps = {"svm": 0.1, "garch": 0.01, "lgssm": 0.1}[model]
+    sampler = Sampler(n=1, m=1, observations=y, parameters=default_params(model))
+    np.random.seed(77)
+    cmp(vec(model, sampler.noisy_gradient(kind="pf", pf="poyiadjis_N", N=100, subsequence_length=10,
+                                         buffer_length=3, minibatch_size=2)), g[model + "/minibatch2"])
+    seqs = [y[0:60], y[60:95], y[95:160], y[160:200]]
+    for nseq in (1, -1):
+        sampler = SeqSampler(n=1, m=1, observations=seqs, parameters=default_params(model))
+        np.random.seed(99 + nseq)
+        cmp(vec(model, sampler.noisy_gradient(kind="pf", pf="poyiadjis_N", N=150, subsequence_length=16,
+                                             buffer_length=4, num_sequences=nseq)),
+            g["{0}/seq_grad_{1}".format(model, nseq)])
+        np.random.seed(199 + nseq)
+        traj = [sampler.parameters.theta()]
+        for _ in range(3):
+            sampler.sample_sgld(epsilon=eps * 0.1, kind="pf", pf="poyiadjis_N", N=150,
+                                subsequence_length=16, buffer_length=4, num_sequences=nseq)
+            sampler.project_parameters()
+            traj.append(sampler.parameters.theta())
+        cmp(np.array(traj), g["{0}/seq_traj_{1}".format(model, nseq)])
+        k = "{0}/seq_loglike_{1}".format(model, nseq)
+        if k in g:
+            np.random.seed(299 + nseq)
+            cmp(np.float64(sampler.noisy_loglikelihood(kind="pf", pf="poyiadjis_N", N=150,
+                                                       subsequence_length=16, buffer_length=4,
+                                                       num_sequences=nseq)), g[k])
+
+
+@pytest.mark.parametrize("model", ["svm", "garch", "lgssm"])
+def test_seq_sampler_and_minibatch_match_reference(oracle_backend, golden_sampler, model):
+    _check_seq_and_minibatch(golden_sampler, model, exact=True)
+
+
+def test_helper_known_answer(oracle_backend, golden_window):
+    """Helper.pf_gradient_estimate on the SVM T=1000 N=1000 case."""
+    from sgmcmc_ssm_amd.models.svm import SVMHelper
+    m = golden_window.meta[0]
+    p = default_params("svm")
+    fm = dict(log_constant=0.0, mean_precision=np.zeros(1), precision=np.eye(1) / m["prior_var"])
+    helper = SVMHelper(forward_message=fm, **p.dim)
+    np.random.seed(99)
+    g = helper.pf_gradient_estimate(observations=golden_window.get(m["key"], "y").reshape(-1, 1),
+                                    parameters=p, N=1000)
+    np.testing.assert_allclose([g["LRinv_vec"], g["LQinv_vec"], g["A"]],
+                               [5.62738493, 9.88344914, -123.63120925], rtol=0, atol=1e-6)
+
+
+def test_unsupported_paths_raise():
+    y = np.zeros((10, 1))
+    s = SVMSampler(n=1, m=1, observations=y, parameters=default_params("svm"))
+    with pytest.raises(NotImplementedError):
+        s.noisy_gradient(kind="marginal")
+    with pytest.raises(NotImplementedError):
+        s.noisy_gradient(kind="pf", pf="paris", N=10)
+    with pytest.raises(ValueError):
+        s.noisy_gradient(kind="pf", pf="bogus", N=10)
+    with pytest.raises(NotImplementedError):
+        s.noisy_gradient(kind="pf", kernel="optimal", N=10)
+    with pytest.raises(ValueError):
+        s.sample_sgld(epsilon=0.1, preconditioner=object())
+    with pytest.raises(NotImplementedError):
+        SVMSampler(n=2, m=1)
