@@ -155,7 +155,9 @@ int pfg_synchronize(pfg_ctx *ctx);
  *   theta_v += eps*(grad_logprior_v(theta) + ghat_v)/Tscale + sqrt(2 eps) N(0, 1/Tscale)
  * followed by project_parameters.  `outs` is the [B][PFG_OUT_DOUBLES] result array the
  * PF kernel wrote (score column order), `theta` [B][PFG_MAX_THETA] is updated in place.
- * hyper: model-specific prior hyper-parameters, see pfg_prior_hyper. */
+ * hyper: model-specific prior hyper-parameters, see pfg_prior_hyper.  The noise of chain b is
+ * keyed by (seed, chain_offset + b, *step_ctr): a chain's trajectory depends on its GLOBAL
+ * index only, not on how chains are spread over GPUs.  *step_ctr is incremented afterwards. */
 typedef struct pfg_prior_hyper {
     double df_Qinv, scale_Qinv, df_Rinv, scale_Rinv;  /* Wishart on Qinv/Rinv (covariance.py:252-284) */
     double mean_A, var_col_A, mean_C, var_col_C;      /* matrix normal (matrices.py:597-607) */
@@ -163,7 +165,8 @@ typedef struct pfg_prior_hyper {
 } pfg_prior_hyper;
 int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
                            const pfg_prior_hyper *hyper, double epsilon, double Tscale,
-                           uint64_t seed, uint64_t *step_ctr, void *hip_stream);
+                           uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr,
+                           void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -152,16 +152,17 @@ __device__ __forceinline__ double reflect_chol(double L) { return L < 0.0 ? sqrt
 
 __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
                                    const double *__restrict__ outs, pfg_prior_hyper hy, double eps,
-                                   double Tscale, uint64_t seed, const uint64_t *step_ctr) {
+                                   double Tscale, uint64_t seed, uint64_t chain_offset,
+                                   const uint64_t *step_ctr) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double *th = theta + (size_t)b * PFG_MAX_THETA;
     const double *g = outs + (size_t)b * PFG_OUT_DOUBLES;
     const uint64_t step = step_ctr ? *step_ctr : 0ull;
-    pfg::u32x4 r0 = pfg::philox4x32_10({(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5A11u},
-                                       (uint32_t)seed, (uint32_t)(seed >> 32));
-    pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5A12u},
-                                       (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t gid = chain_offset + (uint64_t)b;
+    const uint32_t c1 = (uint32_t)step, c2 = (uint32_t)(step >> 32) ^ (uint32_t)(gid >> 32);
+    pfg::u32x4 r0 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A11u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A12u}, (uint32_t)seed, (uint32_t)(seed >> 32));
     const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps);
     double nz[4] = {pfg::normal_bm<double>(r0.x, r0.y), pfg::normal_bm<double>(r0.z, r0.w),
                     pfg::normal_bm<double>(r1.x, r1.y), pfg::normal_bm<double>(r1.z, r1.w)};
@@ -285,7 +286,7 @@ int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, i
 
 int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
                            const pfg_prior_hyper *hyper, double epsilon, double Tscale, uint64_t seed,
-                           uint64_t *step_ctr, void *hip_stream) {
+                           uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
     if (!theta || !outs || !hyper) return fail(ctx, PFG_ERR_INVALID, "pfg_sgld_update_device: NULL argument");
     if (model < 0 || model > 2) return fail(ctx, PFG_ERR_INVALID, "Unrecognized model id");
@@ -294,7 +295,7 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     hipLaunchKernelGGL(sgld_update_kernel, dim3((B + 127) / 128), dim3(128), 0, st, model, B, theta, outs,
-                       *hyper, epsilon, Tscale, seed, (const uint64_t *)step_ctr);
+                       *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr);
     if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;

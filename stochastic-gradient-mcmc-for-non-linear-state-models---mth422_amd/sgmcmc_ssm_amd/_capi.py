@@ -131,7 +131,7 @@ def load_library():
     lib.pfg_synchronize.restype = C.c_int
     lib.pfg_sgld_update_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                            C.POINTER(PriorHyper), C.c_double, C.c_double, C.c_uint64,
-                                           C.c_void_p, C.c_void_p]
+                                           C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pfg_sgld_update_device.restype = C.c_int
     _lib = lib
     return lib
@@ -267,11 +267,11 @@ class Context:
                                                C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def sgld_update_device(self, model, B, theta_ptr, outs_ptr, hyper, epsilon, Tscale, seed,
-                           step_ctr_ptr=None, stream_ptr=None):
+                           chain_offset=0, step_ctr_ptr=None, stream_ptr=None):
         self._check(self.lib.pfg_sgld_update_device(
             self.handle, MODEL[model], int(B), C.c_void_p(theta_ptr), C.c_void_p(outs_ptr), C.byref(hyper),
             float(epsilon), float(Tscale), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
-            C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
+            C.c_uint64(int(chain_offset)), C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
             C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def variant_name(self, model, kernel, dtype, rng, n_max):

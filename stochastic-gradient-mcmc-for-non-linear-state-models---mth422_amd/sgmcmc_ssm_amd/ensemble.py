@@ -213,7 +213,7 @@ class ChainEnsemble(object):
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
         self.ctx.sgld_update_device(self.model, self.C, self.theta_dev.data_ptr(), self.out_dev.data_ptr(),
                                     self.hyper, self.epsilon, float(self.T), self.seed ^ 0x5DEECE66D,
-                                    self.step_ctr.data_ptr(), st)
+                                    self.chain_offset, self.step_ctr.data_ptr(), st)
 
     def step(self, num_steps=1):
         """num_steps x (sample_sgld + project_parameters) for every chain.  Asynchronous."""
