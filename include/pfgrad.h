@@ -139,8 +139,12 @@ const char *pfg_last_error(pfg_ctx *ctx);   /* ctx may be NULL: last error of pf
 int pfg_run(pfg_ctx *ctx, const pfg_problem *p, pfg_result *r);
 int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs);
 
+/* The context's own (non-blocking) stream, as a hipStream_t. */
+void *pfg_ctx_stream(pfg_ctx *ctx);
+
 /* Resident entry point: `dev_probs` is a DEVICE array of B descriptors; launches on
- * `hip_stream` (a hipStream_t, NULL = the ctx stream) and returns without synchronising.
+ * `hip_stream` (a hipStream_t used as is: NULL is HIP's default stream; pass
+ * pfg_ctx_stream(ctx) for the context's own) and returns without synchronising.
  * n_max = the largest N in the batch (selects the kernel variant). */
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);

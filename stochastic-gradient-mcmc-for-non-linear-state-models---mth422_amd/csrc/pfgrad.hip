@@ -258,6 +258,8 @@ void pfg_destroy(pfg_ctx *ctx) {
     delete ctx;
 }
 
+void *pfg_ctx_stream(pfg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 int pfg_synchronize(pfg_ctx *ctx) {
     if (!ctx) return PFG_ERR_INVALID;
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -280,8 +282,7 @@ int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, i
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device: dev_probs is NULL");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, st);
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream);
 }
 
 int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
@@ -293,7 +294,7 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
     if (!(epsilon > 0.0) || !(Tscale > 0.0)) return fail(ctx, PFG_ERR_INVALID, "epsilon and Tscale must be > 0");
     if (B <= 0) return PFG_OK;
     PFG_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(sgld_update_kernel, dim3((B + 127) / 128), dim3(128), 0, st, model, B, theta, outs,
                        *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr);
     if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);

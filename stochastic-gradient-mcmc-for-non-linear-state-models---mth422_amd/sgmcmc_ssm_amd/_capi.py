@@ -74,7 +74,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 ], align=True)
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
-           "pfg_launch_device", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
+           "pfg_ctx_stream", "pfg_launch_device", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device")
 
 _lib = None
@@ -101,6 +101,15 @@ def load_library():
         raise RuntimeError(
             "libpfgrad.so is not built ({0}). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python -m sgmcmc_ssm_amd._build`; there is no CPU fallback.".format(path))
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (ROCm 7.0 here)
+    # while libpfgrad.so was linked against the system one (ROCm 7.2, same SONAME).  Whichever
+    # is loaded first serves both; loading the system runtime first breaks torch.cuda.  So when
+    # torch is installed, let it load its runtime before we dlopen (torch is only plumbing:
+    # device memory, streams, torch.distributed -- no torch type crosses the C ABI).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.pfg_version.restype = C.c_int
     lib.pfg_struct_size.argtypes = [C.c_int]
@@ -123,6 +132,8 @@ def load_library():
     lib.pfg_launch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]
     lib.pfg_launch_device.restype = C.c_int
+    lib.pfg_ctx_stream.argtypes = [C.c_void_p]
+    lib.pfg_ctx_stream.restype = C.c_void_p
     lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
@@ -261,18 +272,24 @@ class Context:
         return outs
 
     # ---- resident path ---------------------------------------------------------------------
-    def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=None):
+    def stream(self):
+        """The context's own hipStream_t (as an integer handle)."""
+        return self.lib.pfg_ctx_stream(self.handle) or 0
+
+    def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=0):
+        """stream_ptr: a hipStream_t handle used as is (0 = HIP's default stream, which is also
+        torch's default `torch.cuda.current_stream().cuda_stream`)."""
         self._check(self.lib.pfg_launch_device(self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype],
                                                RNG[rng], int(n_max), int(B), C.c_void_p(dev_probs_ptr),
-                                               C.c_void_p(stream_ptr) if stream_ptr else None))
+                                               C.c_void_p(int(stream_ptr))))
 
     def sgld_update_device(self, model, B, theta_ptr, outs_ptr, hyper, epsilon, Tscale, seed,
-                           chain_offset=0, step_ctr_ptr=None, stream_ptr=None):
+                           chain_offset=0, step_ctr_ptr=None, stream_ptr=0):
         self._check(self.lib.pfg_sgld_update_device(
             self.handle, MODEL[model], int(B), C.c_void_p(theta_ptr), C.c_void_p(outs_ptr), C.byref(hyper),
             float(epsilon), float(Tscale), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
             C.c_uint64(int(chain_offset)), C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
-            C.c_void_p(stream_ptr) if stream_ptr else None))
+            C.c_void_p(int(stream_ptr))))
 
     def variant_name(self, model, kernel, dtype, rng, n_max):
         return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()
