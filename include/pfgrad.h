@@ -54,8 +54,9 @@ enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2 };
 /* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
 enum pfg_dtype { PFG_F64 = 0, PFG_F32 = 1 };
 /* REPLAY: caller supplies the NumPy legacy stream (z0[N], u[T*N], z[T*N]) -> results
- * reproduce the reference on the same seed.  PHILOX: counter-based device generator. */
-enum pfg_rng { PFG_RNG_REPLAY = 0, PFG_RNG_PHILOX = 1 };
+ * reproduce the reference on the same seed.  DEVICE: generated in the kernel: one
+ * xoshiro128++ per lane keyed by Philox4x32-10(seed; lane, stream, *step_ctr). */
+enum pfg_rng { PFG_RNG_REPLAY = 0, PFG_RNG_DEVICE = 1 };
 
 enum pfg_status {
     PFG_OK = 0,
@@ -82,8 +83,8 @@ typedef struct pfg_problem {
     const double *y;         /* [T] observations (m = 1) */
     const double *weights;   /* [tL-t1] importance weights or NULL (= 1) */
     const double *theta;     /* raw parameters, model layout above */
-    const double *z0, *u, *z;/* REPLAY streams: [N], [T*N], [T*N]; NULL for PHILOX */
-    uint64_t seed, stream;   /* PHILOX key and stream id */
+    const double *z0, *u, *z;/* REPLAY streams: [N], [T*N], [T*N]; NULL for DEVICE */
+    uint64_t seed, stream;   /* DEVICE rng: key and stream id (global chain id) */
     const double *init_x, *init_logw, *init_stats; /* optional warm start: [N*n],[N],[N*h] */
 } pfg_problem;
 
@@ -115,7 +116,7 @@ typedef struct pfg_dev_problem {
                                 max log weight m_T, min |u - cdf| tie margin (REPLAY) */
     double *final_x, *final_logw, *final_stats;
     double *trace_x, *trace_logw, *trace_stats, *trace_ll;
-    const uint64_t *step_ctr;/* optional: *step_ctr is mixed into the PHILOX counter */
+    const uint64_t *step_ctr;/* optional: *step_ctr is mixed into the DEVICE rng key */
     void *scratch;           /* large-N variant: per-problem state buffers, else NULL */
     double prior_mean, prior_var, lambduh;
     uint64_t seed, stream;

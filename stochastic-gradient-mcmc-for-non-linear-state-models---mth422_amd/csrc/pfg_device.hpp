@@ -8,40 +8,62 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "pfgrad.h"
 
 namespace pfg {
 
 constexpr int WAVE = 64;
 constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
-constexpr double TWO_PI = 6.283185307179586;
 
 // ------------------------------------------------------------------------------------
-// wave-level primitives (64 lanes)
+// wave-level primitives (64 lanes) on DPP: row_shr 1,2,4,8 inside 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows (gfx9 cross-lane modes; no LDS traffic).
+// A lane whose DPP source does not exist keeps `old`, the operation's identity.
 // ------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        T o = __shfl_xor(v, d, WAVE);
-        v = o > v ? o : v;
-    }
-    return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ double bcast_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ float bcast_lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+// inclusive prefix sum over the wave; lane 63 ends with the wave total
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2,3
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) { return bcast_lane63(wave_incl_scan(v)); }
 
-__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        double o = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += o;
-    }
-    return v;
+__device__ __forceinline__ double wave_max(double v) {
+#define PFG_MAX_STEP(CTRL, RM) { double o = dpp_f64<CTRL, RM>(v, v); v = o > v ? o : v; }
+    PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)
+    PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
+#undef PFG_MAX_STEP
+    return bcast_lane63(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#define PFG_MAX_STEP(CTRL, RM) { float o = dpp_f32<CTRL, RM>(v, v); v = o > v ? o : v; }
+    PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)
+    PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
+#undef PFG_MAX_STEP
+    return bcast_lane63(v);
 }
 
 // ------------------------------------------------------------------------------------
@@ -62,25 +84,52 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
-// 53-bit uniform in [0,1) from two words, the construction NumPy's random_sample uses
-__device__ __forceinline__ double u01_53(uint32_t a, uint32_t b) {
-    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+// ------------------------------------------------------------------------------------
+// Device RNG (PFG_RNG_DEVICE): one xoshiro128++ generator per lane (Blackman & Vigna 2019;
+// adds / xors / rotates only -- 32-bit multiplies are quarter-rate on CDNA), its 128-bit state
+// keyed by Philox4x32-10(seed; lane, stream = global chain id, step counter), so streams are
+// reproducible and independent of how chains are spread over GPUs.
+// ------------------------------------------------------------------------------------
+struct LaneRng {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t sum = s0 + s3;
+        const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+};
+
+__device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream, uint64_t step, uint32_t lane) {
+    u32x4 r = philox4x32_10({lane, (uint32_t)step, (uint32_t)stream,
+                             (uint32_t)(stream >> 32) ^ (uint32_t)(step >> 32)},
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    LaneRng g;
+    g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w | 1u;   // never the all-zero state
+    return g;
 }
 
-// standard normal by Box-Muller from two words
-template <typename REAL>
-__device__ __forceinline__ REAL normal_bm(uint32_t a, uint32_t b);
-template <>
-__device__ __forceinline__ double normal_bm<double>(uint32_t a, uint32_t b) {
-    double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0);     // (0,1]
-    double u2 = (double)b * (1.0 / 4294967296.0);             // [0,1)
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+// uniform in (0,1) with 32 random bits (resampling needs resolution << 1/N only)
+__device__ __forceinline__ double u01_32(uint32_t a) { return ((double)a + 0.5) * (1.0 / 4294967296.0); }
+
+// two independent standard normals from two words (Box-Muller, both branches used)
+__device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) {
+    const double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0);     // (0,1]
+    const double u2 = (double)b * (1.0 / 2147483648.0);             // [0,2): angle / pi
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(u2, &sn, &cs);
+    z0 = r * cs; z1 = r * sn;
 }
-template <>
-__device__ __forceinline__ float normal_bm<float>(uint32_t a, uint32_t b) {
-    float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1], 24 bits
-    float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * __logf(u1)) * cospif(2.0f * u2);
+__device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1], 24 bits
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi
+    const float r = sqrtf(-2.0f * __logf(u1));
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions
+    z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // ------------------------------------------------------------------------------------
@@ -155,11 +204,11 @@ __device__ __forceinline__ double sqrt_r(double v) { return sqrt(v); }
 __device__ __forceinline__ float sqrt_r(float v) { return sqrtf(v); }
 
 // One particle: parent state xp -> proposal x' (Kernel.rv), log weight (Kernel.reweight) and
-// additive statistic (score or sufficient statistic), all from the same registers.
-// stat: PFG_STAT_*; `inside` = t in [t1,tL).  add[] is NOT yet scaled by weight_t.
-template <int MODEL, int KERNEL, typename REAL>
+// additive statistic (STAT = PFG_STAT_SCORE: complete-data score; otherwise the sufficient
+// statistics), all from the same registers, straight-line.  add[] is NOT yet scaled by weight_t.
+template <int MODEL, int KERNEL, int STAT, typename REAL>
 __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL *xp, REAL y, REAL z,
-                                              int stat, bool inside, REAL *xn, REAL &lw, REAL *add) {
+                                              REAL *xn, REAL &lw, REAL *add) {
     constexpr int H = ModelDims<MODEL>::H;
     const REAL half = (REAL)0.5;
 #pragma unroll
@@ -172,16 +221,14 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL 
         REAL y2 = y * y;
         lw = ((c.c0 + ((-half * y2) * e) * c.Rinv) + c.logLRinv) + (-half * x1);
         xn[0] = x1;
-        if (inside) {
-            if (stat == PFG_STAT_SCORE) {
-                REAL dx = x1 - c.A * xp[0];
-                add[2] = (c.Qinv * dx) * xp[0];
-                add[1] = c.iLQinv - (dx * dx) * c.LQinv;
-                REAL dy2 = y2 * e;                       // y^2 / exp(x')
-                add[0] = c.iLRinv - dy2 * c.LRinv;
-            } else if (stat == PFG_STAT_SUFF) {
-                add[0] = x1; add[1] = x1 * x1; add[2] = xp[0] * x1;
-            }
+        if (STAT == PFG_STAT_SCORE) {
+            REAL dx = x1 - c.A * xp[0];
+            add[2] = (c.Qinv * dx) * xp[0];
+            add[1] = c.iLQinv - (dx * dx) * c.LQinv;
+            REAL dy2 = y2 * e;                       // y^2 / exp(x')
+            add[0] = c.iLRinv - dy2 * c.LRinv;
+        } else {
+            add[0] = x1; add[1] = x1 * x1; add[2] = xp[0] * x1;
         }
     } else if (MODEL == PFG_MODEL_LGSSM) {
         REAL x1;
@@ -198,18 +245,16 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL 
             lw = ((-half * (diff * diff)) / c.opt_var - half * (REAL)LOG_2PI) - half * c.opt_logvar;
         }
         xn[0] = x1;
-        if (inside) {
-            if (stat == PFG_STAT_SCORE) {
-                // lgssm/helper.py:1270-1277, order [LRinv, LQinv, C, A]
-                REAL dx = x1 - c.A * xp[0];
-                add[3] = (c.Qinv * dx) * xp[0];
-                add[1] = c.iLQinv - (dx * dx) * c.LQinv;
-                REAL dy = y - c.C * x1;
-                add[2] = (c.Rinv * dy) * x1;
-                add[0] = c.iLRinv - (dy * dy) * c.LRinv;
-            } else if (stat == PFG_STAT_SUFF) {
-                add[0] = x1; add[1] = x1 * x1; add[2] = xp[0] * x1;
-            }
+        if (STAT == PFG_STAT_SCORE) {
+            // lgssm/helper.py:1270-1277, order [LRinv, LQinv, C, A]
+            REAL dx = x1 - c.A * xp[0];
+            add[3] = (c.Qinv * dx) * xp[0];
+            add[1] = c.iLQinv - (dx * dx) * c.LQinv;
+            REAL dy = y - c.C * x1;
+            add[2] = (c.Rinv * dy) * x1;
+            add[0] = c.iLRinv - (dy * dy) * c.LRinv;
+        } else {
+            add[0] = x1; add[1] = x1 * x1; add[2] = xp[0] * x1;
         }
     } else {
         // garch/kernels.py:60-68 / :146-156, reweight :83-88 / :172-178
@@ -228,43 +273,47 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL 
             lw = (c.c0 + (-half * (y * y)) / v2) + (-half * log_r(v2));
         }
         xn[0] = x1; xn[1] = s2;
-        if (inside) {
-            if (stat == PFG_STAT_SCORE) {
-                // garch/helper.py:350-370, order [LRinv, log_mu, logit_phi, logit_lambduh]
-                REAL v = s2;
-                REAL gv = (-half * (v - x1 * x1)) / (v * v);
-                add[1] = (gv * ((REAL)1 - c.phi)) * c.mu;
-                add[2] = ((gv * ((-c.mu + c.lam * xx) + ((REAL)1 - c.lam) * xp[1])) * ((REAL)1 - c.phi)) * c.phi;
-                add[3] = (((gv * c.phi) * (xx - xp[1])) * ((REAL)1 - c.lam)) * c.lam;
-                REAL dy = y - x1;
-                add[0] = c.iLRinv - (dy * dy) * c.LRinv;
-            } else if (stat == PFG_STAT_SUFF) {
-                REAL x2 = x1 * x1;
-                add[0] = x1; add[1] = x2; add[2] = x2 * x2;
-            }
+        if (STAT == PFG_STAT_SCORE) {
+            // garch/helper.py:350-370, order [LRinv, log_mu, logit_phi, logit_lambduh]
+            REAL v = s2;
+            REAL gv = (-half * (v - x1 * x1)) / (v * v);
+            add[1] = (gv * ((REAL)1 - c.phi)) * c.mu;
+            add[2] = ((gv * ((-c.mu + c.lam * xx) + ((REAL)1 - c.lam) * xp[1])) * ((REAL)1 - c.phi)) * c.phi;
+            add[3] = (((gv * c.phi) * (xx - xp[1])) * ((REAL)1 - c.lam)) * c.lam;
+            REAL dy = y - x1;
+            add[0] = c.iLRinv - (dy * dy) * c.LRinv;
+        } else {
+            REAL x2 = x1 * x1;
+            add[0] = x1; add[1] = x2; add[2] = x2 * x2;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------
-// LDS-resident kernel: N <= NT*PPT particles, particle i = k*NT + tid held by thread tid in
-// register slot k.  LDS: cdf[NL] f64 | x[NS][NL] | stats[H][NL] | reduction scratch.
-// 4 workgroup barriers per timestep.
+// LDS-resident kernel: N <= NT*PPT particles; particle i = k*NT + tid belongs to thread tid,
+// slot k.  Only the log-weights live in registers across timesteps; particles and statistics
+// live in LDS as struct-of-arrays over the particle axis (lane i <-> particle i: conflict-free).
+//   LDS: cdf[NL] f64 | buf0 {x[NS][NL], stats[H][NL]} | buf1 (PP only) | reduction scratch
+// PP = ping-pong state buffers: children are written to the other buffer, so no barrier is
+// needed between gathering parents and publishing children (3 barriers per timestep, and a
+// slot's parent state dies as soon as its child is computed).  PP = false keeps ONE buffer
+// (larger N fits in 160 KiB) at the price of a 4th barrier and of holding all gathered
+// parents in registers across it.
 // ------------------------------------------------------------------------------------
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;
     static constexpr int RED = PPT * NW + NW + PFG_MAX_STAT * NW + 8;  // doubles of scratch
 };
 
-template <int MODEL, typename REAL, int NT, int PPT>
+template <int MODEL, typename REAL, int NT, int PPT, bool PP>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
-    int NL = (N + WAVE - 1) / WAVE * WAVE;
-    return (size_t)NL * 8 + (size_t)NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
+    size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
+    return NL * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
-__global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT >= 4096 || NT >= 1024) ? 4 : 2))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NW = NT / WAVE;
@@ -273,17 +322,23 @@ __global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__res
     const pfg_dev_problem &P = probs[blockIdx.x];
     const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
     const int NL = (N + WAVE - 1) / WAVE * WAVE;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
     const int stat = P.stat;
     const double lam_d = is_filter ? 0.0 : P.lambduh;
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
+    const double *__restrict__ const yv = P.y;
+    const double *__restrict__ const wv = P.weights;
+    const double *__restrict__ const uv = P.u;
+    const double *__restrict__ const zv = P.z;
 
     double *cdf = reinterpret_cast<double *>(smem);
-    REAL *xL = reinterpret_cast<REAL *>(cdf + NL);
-    REAL *sL = xL + (size_t)NS * NL;
-    double *red = reinterpret_cast<double *>(sL + (size_t)H * NL);
+    REAL *buf0 = reinterpret_cast<REAL *>(cdf + NL);
+    const size_t bufsz = (size_t)(NS + H) * NL;
+    REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
+    double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
     double *red_scan = red;                 // [PPT*NW]
     double *red_max = red + PPT * NW;       // [NW]
     double *red_S = red_max + NW;           // [H*NW]
@@ -292,110 +347,133 @@ __global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__res
     int np2 = 1;
     while (np2 < N) np2 <<= 1;
 
-    const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
-    const uint64_t stepc = P.step_ctr ? *P.step_ctr : 0ull;
-    const uint32_t ctr_z = (uint32_t)P.stream ^ (uint32_t)(stepc << 20);
-    const uint32_t ctr_w = (uint32_t)(P.stream >> 32) ^ (uint32_t)(stepc >> 12);
+    LaneRng rng = {};
+    if (RNG == PFG_RNG_DEVICE)
+        rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
+    // PPT standard normals for this thread's slots (device RNG)
+    auto draw_normals = [&](REAL *zz) {
+#pragma unroll
+        for (int k = 0; k < PPT; k += 2) {
+            REAL a, b;
+            normal_pair(rng.next(), rng.next(), a, b);
+            zz[k] = a;
+            if (k + 1 < PPT) zz[k + 1] = b;
+        }
+    };
 
-    REAL x[PPT][NS], lw[PPT], s[PPT][H];
+    REAL lw[PPT];
     // ---- x0 (kernels.py:83-100, garch/kernels.py:7-18) or warm start ------------------
     {
         double pv = P.prior_var;
         if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
             pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
         const double sd = sqrt(pv);
+        REAL z0[PPT];
+        if (RNG == PFG_RNG_DEVICE) draw_normals(z0);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = k * NT + tid;
-            const bool valid = i < N;
-#pragma unroll
-            for (int d = 0; d < NS; ++d) x[k][d] = (REAL)0;
-#pragma unroll
-            for (int h = 0; h < H; ++h) s[k][h] = (REAL)0;
             lw[k] = (REAL)0;
-            if (valid) {
+            if (i < N) {
+                REAL x[NS], s[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) s[h] = (REAL)0;
                 if (P.init_x) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) x[k][d] = (REAL)P.init_x[(size_t)i * NS + d];
+                    for (int d = 0; d < NS; ++d) x[d] = (REAL)P.init_x[(size_t)i * NS + d];
                     lw[k] = (REAL)P.init_logw[i];
                     if (P.init_stats && !is_filter) {
 #pragma unroll
-                        for (int h = 0; h < H; ++h) s[k][h] = (REAL)P.init_stats[(size_t)i * H + h];
+                        for (int h = 0; h < H; ++h) s[h] = (REAL)P.init_stats[(size_t)i * H + h];
                     }
                 } else {
-                    double z0;
-                    if (RNG == PFG_RNG_REPLAY) z0 = P.z0[i];
-                    else {
-                        u32x4 r = philox4x32_10({(uint32_t)i, 0u, ctr_z, ctr_w}, k0, k1);
-                        z0 = (double)normal_bm<REAL>(r.z, r.w);
-                    }
-                    x[k][0] = (REAL)(P.prior_mean + sd * z0);
+                    const double z = (RNG == PFG_RNG_REPLAY) ? P.z0[i] : (double)z0[k];
+                    x[0] = (REAL)(P.prior_mean + sd * z);
                 }
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xL[(size_t)d * NL + i] = x[k][d];
+                for (int d = 0; d < NS; ++d) cur[(size_t)d * NL + i] = x[d];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sL[(size_t)h * NL + i] = s[k][h];
+                for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NL + i] = s[h];
+                if (P.trace_x) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
+                    P.trace_logw[i] = (double)lw[k];
+                    if (P.trace_stats && !is_filter) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) P.trace_stats[(size_t)i * H + h] = (double)s[h];
+                    }
+                }
             }
         }
     }
-    auto trace_state = [&](int row) {
-        if (!P.trace_x) return;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = k * NT + tid;
-            if (i < N) {
-#pragma unroll
-                for (int d = 0; d < NS; ++d) P.trace_x[((size_t)row * N + i) * NS + d] = (double)x[k][d];
-                P.trace_logw[(size_t)row * N + i] = (double)lw[k];
-                if (P.trace_stats && !is_filter) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h)
-                        P.trace_stats[((size_t)row * N + i) * H + h] = (double)s[k][h];
-                }
-            }
-        }
-    };
-    trace_state(0);
-    if (P.trace_ll && tid == 0) P.trace_ll[0] = 0.0;
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
-    double filt[H];
+    double filt[H], S[H];
 #pragma unroll
-    for (int h = 0; h < H; ++h) filt[h] = 0.0;
-    double S[H];
+    for (int h = 0; h < H; ++h) { filt[h] = 0.0; S[h] = 0.0; }
     double m = 0.0, W = (double)N;
+    // slots beyond N: log-weight -inf (weight exactly 0, never an ancestor); their lanes run the
+    // same straight-line code on clamped indices and only their stores are masked.
+    bool valid[PPT];
+    int own[PPT];                       // own particle index, clamped for reads
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        valid[k] = (k * NT + tid) < N;
+        own[k] = valid[k] ? (k * NT + tid) : (N - 1);
+        if (!valid[k]) lw[k] = -INFINITY;
+    }
+    const int last = N - 1;
 
     for (int t = 0; t <= T; ++t) {
         // ---- (A) block max of the current log weights  (log_normalize, pf.py:374-377) ----
-        REAL ml = -INFINITY;
+        REAL ml = lw[0];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (k * NT + tid < N) ml = lw[k] > ml ? lw[k] : ml;
+        for (int k = 1; k < PPT; ++k) ml = lw[k] > ml ? lw[k] : ml;
         ml = wave_max(ml);
         if (lane == 0) red_max[wave] = (double)ml;
         __syncthreads();                                                        // barrier 1
-        double mm = red_max[0];
+        {
+            double mm = red_max[0];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) mm = red_max[w] > mm ? red_max[w] : mm;
-        m = mm;
+            for (int w = 1; w < NW; ++w) mm = red_max[w] > mm ? red_max[w] : mm;
+            m = mm;
+        }
         // ---- (B) unnormalised weights, (C) prefix scan + weighted statistic sums --------
         const bool needS = needS_every || (t == T);
-        double p[PPT], cs[PPT];
+        double cs[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const bool valid = (k * NT + tid) < N;
-            p[k] = valid ? (double)exp_r((REAL)(lw[k] - (REAL)m)) : 0.0;
-            cs[k] = wave_incl_scan(p[k], lane);
-            if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
-        }
+        for (int k = 0; k < PPT; ++k) cs[k] = (double)exp_r((REAL)(lw[k] - (REAL)m));   // exp(-inf) = 0
         if (needS) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double part = 0.0;
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) part += (double)s[k][h] * p[k];
+                for (int k = 0; k < PPT; ++k) part += (double)cur[(size_t)(NS + h) * NL + own[k]] * cs[k];
                 part = wave_sum(part);
                 if (lane == 0) red_S[h * NW + wave] = part;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            cs[k] = wave_incl_scan(cs[k]);
+            if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
+        }
+        // this step's randomness (independent of the barrier: overlaps the wait)
+        double uu[PPT];
+        REAL zz[PPT];
+        if (t < T) {
+            if (RNG == PFG_RNG_REPLAY) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    uu[k] = uv[(size_t)t * N + own[k]];
+                    zz[k] = (REAL)zv[(size_t)t * N + own[k]];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
+                draw_normals(zz);
             }
         }
         __syncthreads();                                                        // barrier 2
@@ -406,28 +484,29 @@ __global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__res
                 double off = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    if (w == wave) off = run;
+                    off = (w == wave) ? run : off;
                     run += red_scan[k * NW + w];
                 }
                 cs[k] += off;
             }
             W = run;
         }
-#pragma unroll
-        for (int h = 0; h < H; ++h) S[h] = 0.0;
+        const double invW = 1.0 / W;
         if (needS) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double acc = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) acc += red_S[h * NW + w];
-                S[h] = acc / W;
+                S[h] = acc * invW;
             }
         }
         // log-likelihood increment of the step that produced these weights
-        // (buffered_smoother.py:124-126): log(mean(exp(logw))) = m + log(W/N)
-        if (t > 0 && (t - 1) >= t1 && (t - 1) < tL) ll += wt_prev * (m + log(W / (double)N));
-        if (P.trace_ll && tid == 0) P.trace_ll[t] = ll;
+        // (buffered_smoother.py:124-126): log(mean(exp(logw))) = m + log(W/N).  Wave 0 only.
+        if (wave == 0) {
+            if (t > 0 && (t - 1) >= t1 && (t - 1) < tL) ll += wt_prev * (m + log(W / (double)N));
+            if (P.trace_ll && tid == 0) P.trace_ll[t] = ll;
+        }
         if (is_filter && t > 0) {
 #pragma unroll
             for (int h = 0; h < H; ++h) filt[h] += S[h];
@@ -435,82 +514,95 @@ __global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__res
         if (t == T) break;
 
         // ---- (D) normalised CDF to LDS (RandomState.choice: cumsum, /= last) -------------
-        const double y_t = P.y[t];
+        const double y_t = yv[t];
         const bool inside = (t >= t1) && (t < tL);
-        const double wt = (inside && P.weights) ? P.weights[t - t1] : 1.0;
-        double uu[PPT];
-        REAL zz[PPT];
+        const double wt = (inside && wv) ? wv[t - t1] : 1.0;
+        const bool use_stat = inside && (stat != PFG_STAT_NONE);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = k * NT + tid;
-            uu[k] = 0.0; zz[k] = (REAL)0;
-            if (i < N) {
-                if (RNG == PFG_RNG_REPLAY) {
-                    uu[k] = P.u[(size_t)t * N + i];
-                    zz[k] = (REAL)P.z[(size_t)t * N + i];
-                } else {
-                    u32x4 r = philox4x32_10({(uint32_t)i, (uint32_t)(t + 1), ctr_z, ctr_w}, k0, k1);
-                    uu[k] = u01_53(r.x, r.y);
-                    zz[k] = normal_bm<REAL>(r.z, r.w);
-                }
-                cdf[i] = cs[k] / W;
-            }
-        }
+        for (int k = 0; k < PPT; ++k)
+            if (valid[k]) cdf[k * NT + tid] = cs[k] * invW;
         __syncthreads();                                                        // barrier 3
-        // ---- (E) multinomial ancestors: smallest j with cdf[j] > u  (searchsorted 'right')
-        REAL xp[PPT][NS], sp[PPT][H];
+
+        // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
+        // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
+        int anc[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = k * NT + tid;
-            int pos = 0;
-            if (i < N) {
-                const double u = uu[k];
-                for (int step = np2 >> 1; step >= 1; step >>= 1) {
-                    const int idx = pos + step - 1;
-                    if (idx < N && cdf[idx] <= u) pos += step;
-                }
-                pos = pos < N - 1 ? pos : N - 1;
-                if (RNG == PFG_RNG_REPLAY) {
-                    // near-tie margin: how close u came to flipping the ancestor index
-                    double hi = cdf[pos] - u;
-                    double lo = pos > 0 ? u - cdf[pos - 1] : 1.0;
-                    double mg = hi < lo ? hi : lo;
-                    tie = mg < tie ? mg : tie;
-                }
-            }
-            // ---- (F) gather parent state and statistics --------------------------------
+        for (int k = 0; k < PPT; ++k) anc[k] = 0;
+        for (int step = np2 >> 1; step >= 1; step >>= 1) {
 #pragma unroll
-            for (int d = 0; d < NS; ++d) xp[k][d] = xL[(size_t)d * NL + pos];
-            if (!is_filter) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) sp[k][h] = sL[(size_t)h * NL + pos];
-            } else {
-#pragma unroll
-                for (int h = 0; h < H; ++h) sp[k][h] = (REAL)0;
+            for (int k = 0; k < PPT; ++k) {
+                int idx = anc[k] + step - 1;
+                idx = idx < last ? idx : last;
+                anc[k] += (cdf[idx] <= uu[k]) ? step : 0;
             }
         }
-        __syncthreads();                                                        // barrier 4
-        // ---- (G) propose, weight, additive statistic; (H) publish to LDS -----------------
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = k * NT + tid;
-            if (i < N) {
-                REAL add[H];
-                particle_step<MODEL, KERNEL, REAL>(c, xp[k], (REAL)y_t, zz[k], stat, inside, x[k], lw[k], add);
+        for (int k = 0; k < PPT; ++k) anc[k] = anc[k] < last ? anc[k] : last;
+        if (RNG == PFG_RNG_REPLAY) {
+            // near-tie margin: how close u came to flipping an ancestor index
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const double hi = cdf[anc[k]] - uu[k];
+                const double lo = anc[k] > 0 ? uu[k] - cdf[anc[k] - 1] : 1.0;
+                const double mg = hi < lo ? hi : lo;
+                tie = (valid[k] && mg < tie) ? mg : tie;
+            }
+        }
+        // ---- (F) gather parents, (G) propose / weight / statistic, (H) publish children ---
+        auto slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            REAL xp[PPT][NS], sp[PPT][H];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[k][d] = cur[(size_t)d * NL + anc[k]];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
+            }
+            if (!PP) __syncthreads();                                           // barrier 4 (single buffer)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                REAL xn[NS], add[H], lwn;
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
+                lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    REAL a = add[h] * (REAL)wt;
+                    const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
                     // pf.py:175-179 / :78-80
-                    s[k][h] = is_filter ? a : (lam * sp[k][h] + oml * (REAL)S[h]) + a;
+                    const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
+                    sp[k][h] = is_filter ? a : sm;
                 }
+                if (valid[k]) {
+                    const int i = k * NT + tid;
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xL[(size_t)d * NL + i] = x[k][d];
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sL[(size_t)h * NL + i] = s[k][h];
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sp[k][h];
+                }
+            }
+        };
+        if (stat == PFG_STAT_SCORE) slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+        else slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+        if (P.trace_x) {
+            // own children back from LDS (written by this thread: no barrier needed)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (valid[k]) {
+                    const int i = k * NT + tid;
+                    const size_t row = (size_t)(t + 1) * N + i;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NL + i];
+                    P.trace_logw[row] = (double)lw[k];
+                    if (P.trace_stats && !is_filter) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+                            P.trace_stats[row * H + h] = (double)nxt[(size_t)(NS + h) * NL + i];
+                    }
+                }
             }
         }
+        if (PP) { REAL *tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
-        trace_state(t + 1);
     }
 
     // ---- outputs --------------------------------------------------------------------
@@ -533,16 +625,18 @@ __global__ __launch_bounds__(NT) void pf_reg_kernel(const pfg_dev_problem *__res
         P.out[7] = tie;
     }
     if (P.final_x) {
+        // own entries of the current buffer: written by this thread, no barrier needed
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = k * NT + tid;
             if (i < N) {
 #pragma unroll
-                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)x[k][d];
+                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * NL + i];
                 if (P.final_logw) P.final_logw[i] = (double)lw[k];
                 if (P.final_stats && !is_filter) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)s[k][h];
+                    for (int h = 0; h < H; ++h)
+                        P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * NL + i];
                 }
             }
         }

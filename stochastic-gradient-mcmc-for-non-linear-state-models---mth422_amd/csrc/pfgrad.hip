@@ -58,35 +58,46 @@ int fail(pfg_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 // ---- kernel variants ----------------------------------------------------------------
-struct Variant { int NT, PPT; const char *tag; };
-const Variant kVariants[] = { {256, 1, "wg256x1"}, {256, 4, "wg256x4"}, {1024, 4, "wg1024x4"} };
+// pp = ping-pong LDS state buffers (3 barriers/step); single buffer fits larger N (4 barriers).
+struct Variant { int NT, PPT; bool pp; const char *tag; };
+const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"},
+                              {1024, 4, true, "wg1024x4"}, {1024, 4, false, "wg1024x4s"},
+                              {512, 2, true, "wg512x2"}, {1024, 1, true, "wg1024x1"},
+                              {256, 4, false, "wg256x4s"} };
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr size_t kLdsLimit = 160 * 1024;
 
 int state_dim(int model) { return model == PFG_MODEL_GARCH ? 2 : 1; }
 int stat_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 int theta_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 
-size_t lds_bytes(int model, int dtype, int NT, int PPT, int N) {
+size_t lds_bytes(int model, int dtype, const Variant &v, int N) {
     size_t rs = dtype == PFG_F64 ? 8 : 4;
     size_t NL = (size_t)(N + 63) / 64 * 64;
-    size_t red = (size_t)PPT * (NT / 64) + (NT / 64) + (size_t)PFG_MAX_STAT * (NT / 64) + 8;
-    return NL * 8 + NL * (state_dim(model) + stat_dim(model)) * rs + red * 8;
+    size_t red = (size_t)v.PPT * (v.NT / 64) + (v.NT / 64) + (size_t)PFG_MAX_STAT * (v.NT / 64) + 8;
+    return NL * 8 + (v.pp ? 2 : 1) * NL * (state_dim(model) + stat_dim(model)) * rs + red * 8;
 }
 
-// index into kVariants, or -1 when no LDS-resident variant fits
+// index into kVariants, or -1 when no LDS-resident variant fits.  PFGRAD_VARIANT=<tag> forces a
+// variant (tuning / tests) when it can hold n_max.
 int pick_variant(int model, int dtype, int n_max) {
-    for (int v = 0; v < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++v) {
-        if (n_max <= kVariants[v].NT * kVariants[v].PPT &&
-            lds_bytes(model, dtype, kVariants[v].NT, kVariants[v].PPT, n_max) <= kLdsLimit)
+    if (const char *force = std::getenv("PFGRAD_VARIANT")) {
+        for (int v = 0; v < kNumVariants; ++v)
+            if (!std::strcmp(force, kVariants[v].tag) && n_max <= kVariants[v].NT * kVariants[v].PPT &&
+                lds_bytes(model, dtype, kVariants[v], n_max) <= kLdsLimit)
+                return v;
+    }
+    for (int v = 0; v < 4; ++v) {
+        if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, kVariants[v], n_max) <= kLdsLimit)
             return v;
     }
     return -1;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT>(n_max);
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, PP>(n_max);
     if (lds > 64 * 1024) {
         PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -99,9 +110,13 @@ int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     switch (v) {
-        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
-        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
-        case 2: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG>(ctx, n_max, B, dp, st);
+        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
+        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
+        case 2: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, true>(ctx, n_max, B, dp, st);
+        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st);
+        case 4: return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, true>(ctx, n_max, B, dp, st);
+        case 5: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
+        case 6: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
     }
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
 }
@@ -111,10 +126,10 @@ int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const p
               hipStream_t st) {
     if (dtype == PFG_F64) {
         if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-        return launch_v<MODEL, KERNEL, double, PFG_RNG_PHILOX>(ctx, v, n_max, B, dp, st);
+        return launch_v<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
     }
     if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-    return launch_v<MODEL, KERNEL, float, PFG_RNG_PHILOX>(ctx, v, n_max, B, dp, st);
+    return launch_v<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
 }
 
 int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
@@ -124,7 +139,7 @@ int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
     if (model == PFG_MODEL_SVM && kernel == PFG_KERNEL_OPTIMAL)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "SVM optimal kernel not analytic");   // svm/helper.py:62
     if (dtype != PFG_F64 && dtype != PFG_F32) return fail(ctx, PFG_ERR_INVALID, "bad dtype");
-    if (rng != PFG_RNG_REPLAY && rng != PFG_RNG_PHILOX) return fail(ctx, PFG_ERR_INVALID, "bad rng mode");
+    if (rng != PFG_RNG_REPLAY && rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_INVALID, "bad rng mode");
     return PFG_OK;
 }
 
@@ -164,8 +179,9 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
     pfg::u32x4 r0 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A11u}, (uint32_t)seed, (uint32_t)(seed >> 32));
     pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A12u}, (uint32_t)seed, (uint32_t)(seed >> 32));
     const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps);
-    double nz[4] = {pfg::normal_bm<double>(r0.x, r0.y), pfg::normal_bm<double>(r0.z, r0.w),
-                    pfg::normal_bm<double>(r1.x, r1.y), pfg::normal_bm<double>(r1.z, r1.w)};
+    double nz[4];
+    pfg::normal_pair(r0.x, r0.y, nz[0], nz[1]);
+    pfg::normal_pair(r1.x, r1.y, nz[2], nz[3]);
     if (model == PFG_MODEL_SVM || model == PFG_MODEL_LGSSM) {
         const bool lg = model == PFG_MODEL_LGSSM;
         double A = th[0], C = lg ? th[1] : 1.0, LQ = th[lg ? 2 : 1], LR = th[lg ? 3 : 2];

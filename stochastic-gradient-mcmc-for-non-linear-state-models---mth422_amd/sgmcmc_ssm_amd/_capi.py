@@ -15,7 +15,7 @@ KERNEL = {"prior": 0, "optimal": 1}
 SMOOTHER = {"nemeth": 0, "filter": 1}
 STAT = {"score": 0, "suff": 1, "none": 2}
 DTYPE = {"f64": 0, "f32": 1}
-RNG = {"replay": 0, "philox": 1}
+RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
 MAX_STAT, MAX_THETA, OUT_DOUBLES = 4, 4, 8
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}

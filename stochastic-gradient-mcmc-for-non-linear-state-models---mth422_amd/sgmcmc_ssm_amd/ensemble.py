@@ -206,7 +206,7 @@ class ChainEnsemble(object):
         """Enqueue one particle-filter launch for all chains on `stream` (default: torch's
         current stream).  Results land in self.out_dev[C, 8] (score columns, loglik)."""
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        self.ctx.launch_device(self.model, self.kernel, self.dtype, "philox", self.N, self.C,
+        self.ctx.launch_device(self.model, self.kernel, self.dtype, "device", self.N, self.C,
                                self.desc_dev.data_ptr(), st)
 
     def launch_update(self, stream=None):

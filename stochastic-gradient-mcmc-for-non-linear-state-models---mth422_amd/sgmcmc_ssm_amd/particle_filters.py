@@ -10,8 +10,9 @@ RNG modes
       legacy `np.random` state are drawn here, in the same order (N normals for x0, then per
       timestep N uniforms for np.random.choice and N normals for Kernel.rv), and handed to the
       kernel.  Results then reproduce the reference on identical seeds (fp64).
-  rng='philox': counter-based generator on the device (no host stream, no H2D traffic); the
-      fast path, statistically equivalent, not seed-compatible with the reference.
+  rng='device' (alias 'philox'): generated inside the kernel (one xoshiro128++ per lane keyed
+      by Philox4x32-10 of (seed, stream, step)): no host stream, no H2D traffic; the fast path,
+      statistically equivalent, not seed-compatible with the reference.
 
 There is no NumPy fallback: without libpfgrad.so and an MI355X every entry point raises.
 """
@@ -52,7 +53,7 @@ def draw_replay_streams(N, T, random_state=None):
     return z0, u, z
 
 
-_philox_calls = [0]
+_device_rng_calls = [0]
 
 
 def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weights=None,
@@ -76,14 +77,14 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
              y=y, weights=weights, theta=theta, flags=flags)
     if rng == "replay":
         q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state)
-    elif rng == "philox":
+    elif rng in ("device", "philox"):
         if seed is None:
             # derive the device key from the host stream so np.random.seed() still controls runs
             rs = np.random if random_state is None else random_state
             seed = int(rs.randint(0, 2 ** 31 - 1)) | (int(rs.randint(0, 2 ** 31 - 1)) << 31)
         if stream is None:
-            _philox_calls[0] += 1
-            stream = _philox_calls[0]
+            _device_rng_calls[0] += 1
+            stream = _device_rng_calls[0]
         q["seed"], q["stream"] = int(seed), int(stream)
     else:
         raise ValueError("Unrecognized rng = {0}".format(rng))

@@ -8,7 +8,7 @@ T, N = 1000, 1000
 y = rs.normal(size=T)
 def run(B, dtype, model="svm", kernel="prior", N=N, T=T):
     th = {"svm":[0.95,1.4,1.4],"garch":[0.0,2.0,2.0,1.8],"lgssm":[0.9,1.0,1.2,1.0]}[model]
-    probs = [dict(model=model, kernel=kernel, dtype=dtype, rng="philox", N=N, y=y[:T], theta=th, seed=1, stream=b,
+    probs = [dict(model=model, kernel=kernel, dtype=dtype, rng="device", N=N, y=y[:T], theta=th, seed=1, stream=b,
                   prior_var=1.0) for b in range(B)]
     ctx.run_batch(probs[:1])
     t = time.time(); o = ctx.run_batch(probs); dt = time.time()-t
