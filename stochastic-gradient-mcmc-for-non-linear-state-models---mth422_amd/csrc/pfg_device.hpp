@@ -115,21 +115,136 @@ __device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream,
 // uniform in (0,1) with 32 random bits (resampling needs resolution << 1/N only)
 __device__ __forceinline__ double u01_32(uint32_t a) { return ((double)a + 0.5) * (1.0 / 4294967296.0); }
 
-// two independent standard normals from two words (Box-Muller, both branches used)
-__device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) {
-    const double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0);     // (0,1]
-    const double u2 = (double)b * (1.0 / 2147483648.0);             // [0,2): angle / pi
-    const double r = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(u2, &sn, &cs);
-    z0 = r * cs; z1 = r * sn;
+// ------------------------------------------------------------------------------------
+// fp64 elementary functions on small LDS tables.  ocml's exp / log / sincospi cost 42 / 98 / 70
+// VALU instructions each (half of them re-materialising polynomial coefficients); the table
+// forms below need 17 / 20 / 17 and one LDS read, at <= 2 ulp -- well inside the parity
+// tolerance.  Tables are filled once per workgroup with ocml.  Explicit fma(): the file is
+// compiled with -ffp-contract=off.
+//   e2[j] = 2^(j/128)                                   j < 128
+//   lg[j] = {1/c_j, log c_j},  c_j = 1 + (j+0.5)/128    j < 128
+//   sc[j] = {sin, cos}(2 pi (j+0.5)/256)                j < 256
+// ------------------------------------------------------------------------------------
+constexpr int TAB_E2 = 128, TAB_LG = 128, TAB_SC = 256;
+constexpr int TAB_DOUBLES_EXP = TAB_E2 + 2 * TAB_LG, TAB_DOUBLES_RNG = 2 * TAB_SC;   // exp+log always; sincos with the device RNG
+
+struct TabF64 {
+    const double *e2;
+    const double2 *lg;
+    const double2 *sc;
+};
+
+__device__ inline void tab_fill(double *mem, bool with_rng, int tid, int nthreads) {
+    double *lg = mem + TAB_E2, *sc = lg + 2 * TAB_LG;
+    for (int j = tid; j < TAB_E2; j += nthreads) mem[j] = exp2((double)j * (1.0 / 128.0));
+    for (int j = tid; j < TAB_LG; j += nthreads) {
+        const double c = 1.0 + ((double)j + 0.5) * (1.0 / 128.0);
+        lg[2 * j] = 1.0 / c; lg[2 * j + 1] = log(c);
+    }
+    if (with_rng) {
+        for (int j = tid; j < TAB_SC; j += nthreads) {
+            double sn, cs;
+            sincospi(((double)j + 0.5) * (1.0 / 128.0), &sn, &cs);
+            sc[2 * j] = sn; sc[2 * j + 1] = cs;
+        }
+    }
 }
-__device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) {
-    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1], 24 bits
-    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi
-    const float r = sqrtf(-2.0f * __logf(u1));
-    // v_sin_f32 / v_cos_f32 take their argument in revolutions
-    z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
+
+// exp(x), any x (overflow -> inf, underflow -> 0, -inf -> 0)
+__device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e2) {
+    x = fmax(x, -1000.0);
+    const double kd = rint(x * 184.6649652337873);                  // 128/ln2
+    const int k = (int)kd;
+    double r = fma(kd, -0.00541521234663378, x);                     // ln2/128, 32-bit head
+    r = fma(kd, -1.4907929134926466e-12, r);                         //          tail
+    const double t = e2[k & (TAB_E2 - 1)];
+    double p = fma(r, 0.008333333333333333, 0.041666666666666664);   // expm1(r), |r| <= ln2/256
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = p * r;
+    p = fma(p, r, r);
+    return ldexp(fma(t, p, t), k >> 7);
+}
+
+// log(x) for finite x > 0 in the normal range
+__device__ __forceinline__ double log_tab(double x, const double2 *__restrict__ lg) {
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const int e = (int)(hi >> 20) - 1023;
+    const double mant = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(x));
+    const double2 t = lg[(hi >> 13) & (TAB_LG - 1)];
+    const double r = fma(mant, t.x, -1.0);                           // |r| <= 2^-8
+    double p = fma(r, 0.2, -0.25);                                   // log1p(r)
+    p = fma(p, r, 0.3333333333333333);
+    p = fma(p, r, -0.5);
+    p = p * r;
+    p = fma(p, r, r);
+    return fma((double)e, 0.6931471805599453, t.y) + p;
+}
+
+// sqrt(x) for finite x > 0 (no special cases): rsq + one coupled Newton step + correction
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
+template <typename REAL, bool TAB> struct Math;
+template <> struct Math<double, true> {
+    TabF64 t;
+    __device__ __forceinline__ double exp(double x) const { return exp_tab(x, t.e2); }
+    __device__ __forceinline__ double log(double x) const { return log_tab(x, t.lg); }
+    __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    // two independent standard normals from two words (Box-Muller, both branches)
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+        const double lu = log_tab((double)a + 0.5, t.lg) - 22.18070977791825;   // log((a+.5)/2^32)
+        const double r = sqrt_pos(-2.0 * lu);
+        const double2 sc = t.sc[b >> 24];
+        const double dl = (double)((int)(b & 0x00FFFFFFu) - 0x00800000) * 1.4629180792671596e-09;  // 2pi/2^32
+        const double d2 = dl * dl;
+        double sd = fma(d2, 0.008333333333333333, -0.16666666666666666);
+        sd = fma(sd * d2, dl, dl);
+        double cd = fma(d2, -0.001388888888888889, 0.041666666666666664);
+        cd = fma(cd, d2, -0.5);
+        cd = fma(cd, d2, 1.0);
+        z0 = r * fma(sc.y, cd, -(sc.x * sd));        // r cos(theta)
+        z1 = r * fma(sc.x, cd, sc.y * sd);           // r sin(theta)
+    }
+};
+template <> struct Math<double, false> {
+    TabF64 t;
+    __device__ __forceinline__ double exp(double x) const { return ::exp(x); }
+    __device__ __forceinline__ double log(double x) const { return ::log(x); }
+    __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+        const double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
+        const double r = ::sqrt(-2.0 * ::log(u1));
+        double sn, cs;
+        sincospi((double)b * (1.0 / 2147483648.0), &sn, &cs);
+        z0 = r * cs; z1 = r * sn;
+    }
+};
+template <bool TAB> struct Math<float, TAB> {
+    TabF64 t;
+    __device__ __forceinline__ float exp(float x) const { return __expf(x); }
+    __device__ __forceinline__ float log(float x) const { return __logf(x); }
+    __device__ __forceinline__ float sqrt(float x) const { return sqrtf(x); }
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) const {
+        const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1), 24 bits
+        const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi
+        const float r = sqrtf(-2.0f * __logf(u1));
+        // v_sin_f32 / v_cos_f32 take their argument in revolutions
+        z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
+    }
+};
+
+// bytes of LDS math tables a kernel instantiation carries
+template <typename REAL, int RNG, bool TAB>
+__host__ __device__ constexpr size_t tab_bytes() {
+    return (TAB && sizeof(REAL) == 8) ? (size_t)8 * (TAB_DOUBLES_EXP + (RNG == PFG_RNG_DEVICE ? TAB_DOUBLES_RNG : 0)) : 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -196,19 +311,12 @@ __device__ __forceinline__ Consts<REAL> make_consts(const double *__restrict__ t
     return c;
 }
 
-__device__ __forceinline__ double exp_r(double v) { return exp(v); }
-__device__ __forceinline__ float exp_r(float v) { return __expf(v); }
-__device__ __forceinline__ double log_r(double v) { return log(v); }
-__device__ __forceinline__ float log_r(float v) { return __logf(v); }
-__device__ __forceinline__ double sqrt_r(double v) { return sqrt(v); }
-__device__ __forceinline__ float sqrt_r(float v) { return sqrtf(v); }
-
 // One particle: parent state xp -> proposal x' (Kernel.rv), log weight (Kernel.reweight) and
 // additive statistic (STAT = PFG_STAT_SCORE: complete-data score; otherwise the sufficient
 // statistics), all from the same registers, straight-line.  add[] is NOT yet scaled by weight_t.
-template <int MODEL, int KERNEL, int STAT, typename REAL>
-__device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL *xp, REAL y, REAL z,
-                                              REAL *xn, REAL &lw, REAL *add) {
+template <int MODEL, int KERNEL, int STAT, typename REAL, typename MATH>
+__device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH &mth, const REAL *xp,
+                                              REAL y, REAL z, REAL *xn, REAL &lw, REAL *add) {
     constexpr int H = ModelDims<MODEL>::H;
     const REAL half = (REAL)0.5;
 #pragma unroll
@@ -217,7 +325,7 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL 
         // svm/kernels.py:34-37, :56-62; svm/helper.py:342-348
         REAL xpA = xp[0] * c.A;
         REAL x1 = c.iLQinv * z + xpA;
-        REAL e = exp_r(-x1);
+        REAL e = mth.exp(-x1);
         REAL y2 = y * y;
         lw = ((c.c0 + ((-half * y2) * e) * c.Rinv) + c.logLRinv) + (-half * x1);
         xn[0] = x1;
@@ -262,15 +370,15 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const REAL 
         REAL s2 = (c.alpha + c.beta * xx) + c.gamma * xp[1];
         REAL x1;
         if (KERNEL == PFG_KERNEL_PRIOR) {
-            x1 = sqrt_r(s2) * z;
+            x1 = mth.sqrt(s2) * z;
             REAL diff = y - x1;
             lw = (c.c0 + (-half * (diff * diff)) * c.Rinv) + c.logLRinv;
         } else {
             REAL var = (REAL)1 / (c.Rinv + (REAL)1 / s2);
             REAL mean = var * (y * c.Rinv);
-            x1 = mean + sqrt_r(var) * z;
+            x1 = mean + mth.sqrt(var) * z;
             REAL v2 = s2 + c.R;
-            lw = (c.c0 + (-half * (y * y)) / v2) + (-half * log_r(v2));
+            lw = (c.c0 + (-half * (y * y)) / v2) + (-half * mth.log(v2));
         }
         xn[0] = x1; xn[1] = s2;
         if (STAT == PFG_STAT_SCORE) {
@@ -305,11 +413,14 @@ template <int NT, int PPT> struct RegLayout {
     static constexpr int RED = PPT * NW + NW + PFG_MAX_STAT * NW + 8;  // doubles of scratch
 };
 
-template <int MODEL, typename REAL, int NT, int PPT, bool PP>
+// PP variants: cdf has NT*PPT entries (tail = sentinel 2.0 -> unrolled, clamp-free search) and
+// the fp64 math runs on LDS tables; the single-buffer variant spends its LDS on particles.
+template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
-    return NL * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
-           (size_t)RegLayout<NT, PPT>::RED * 8;
+    size_t NC = PP ? (size_t)NT * PPT : NL;
+    return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
+           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, PP>();
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
@@ -334,14 +445,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     const double *__restrict__ const uv = P.u;
     const double *__restrict__ const zv = P.z;
 
+    constexpr bool TAB = PP;            // table math + sentinel-padded cdf ride with ping-pong
+    const int NC = PP ? NT * PPT : NL;
     double *cdf = reinterpret_cast<double *>(smem);
-    REAL *buf0 = reinterpret_cast<REAL *>(cdf + NL);
+    REAL *buf0 = reinterpret_cast<REAL *>(cdf + NC);
     const size_t bufsz = (size_t)(NS + H) * NL;
     REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
     double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
     double *red_scan = red;                 // [PPT*NW]
     double *red_max = red + PPT * NW;       // [NW]
     double *red_S = red_max + NW;           // [H*NW]
+    double *tabmem = red + RegLayout<NT, PPT>::RED;
+
+    Math<REAL, TAB> mth;
+    mth.t.e2 = tabmem;
+    mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
+    mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
+    if (tab_bytes<REAL, RNG, TAB>() > 0) tab_fill(tabmem, RNG == PFG_RNG_DEVICE, tid, NT);
+    if (PP) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (k * NT + tid >= N) cdf[k * NT + tid] = 2.0;      // sentinel: never <= u
+    }
+    __syncthreads();
 
     const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
     int np2 = 1;
@@ -355,7 +481,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
 #pragma unroll
         for (int k = 0; k < PPT; k += 2) {
             REAL a, b;
-            normal_pair(rng.next(), rng.next(), a, b);
+            mth.normal_pair(rng.next(), rng.next(), a, b);
             zz[k] = a;
             if (k + 1 < PPT) zz[k + 1] = b;
         }
@@ -444,7 +570,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         const bool needS = needS_every || (t == T);
         double cs[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) cs[k] = (double)exp_r((REAL)(lw[k] - (REAL)m));   // exp(-inf) = 0
+        for (int k = 0; k < PPT; ++k) cs[k] = (double)mth.exp((REAL)(lw[k] - (REAL)m));   // exp(-inf) = 0
         if (needS) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
@@ -528,12 +654,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         int anc[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = 0;
-        for (int step = np2 >> 1; step >= 1; step >>= 1) {
+        if (PP) {
+            // sentinel-padded cdf: log2(NT*PPT) fixed probes, offsets fold into the ds_read
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                int idx = anc[k] + step - 1;
-                idx = idx < last ? idx : last;
-                anc[k] += (cdf[idx] <= uu[k]) ? step : 0;
+            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + step - 1] <= uu[k]) ? step : 0;
+            }
+        } else {
+            for (int step = np2 >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    int idx = anc[k] + step - 1;
+                    idx = idx < last ? idx : last;
+                    anc[k] += (cdf[idx] <= uu[k]) ? step : 0;
+                }
             }
         }
 #pragma unroll
@@ -563,7 +698,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 REAL xn[NS], add[H], lwn;
-                particle_step<MODEL, KERNEL, STAT, REAL>(c, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
                 lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {

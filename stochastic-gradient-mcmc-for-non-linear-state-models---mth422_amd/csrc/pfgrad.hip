@@ -71,24 +71,27 @@ int state_dim(int model) { return model == PFG_MODEL_GARCH ? 2 : 1; }
 int stat_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 int theta_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 
-size_t lds_bytes(int model, int dtype, const Variant &v, int N) {
+size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
     size_t rs = dtype == PFG_F64 ? 8 : 4;
     size_t NL = (size_t)(N + 63) / 64 * 64;
+    size_t NC = v.pp ? (size_t)v.NT * v.PPT : NL;
     size_t red = (size_t)v.PPT * (v.NT / 64) + (v.NT / 64) + (size_t)PFG_MAX_STAT * (v.NT / 64) + 8;
-    return NL * 8 + (v.pp ? 2 : 1) * NL * (state_dim(model) + stat_dim(model)) * rs + red * 8;
+    size_t tab = (v.pp && dtype == PFG_F64)
+                     ? 8 * (size_t)(pfg::TAB_DOUBLES_EXP + (rng == PFG_RNG_DEVICE ? pfg::TAB_DOUBLES_RNG : 0)) : 0;
+    return NC * 8 + (v.pp ? 2 : 1) * NL * (state_dim(model) + stat_dim(model)) * rs + red * 8 + tab;
 }
 
 // index into kVariants, or -1 when no LDS-resident variant fits.  PFGRAD_VARIANT=<tag> forces a
 // variant (tuning / tests) when it can hold n_max.
-int pick_variant(int model, int dtype, int n_max) {
+int pick_variant(int model, int dtype, int rng, int n_max) {
     if (const char *force = std::getenv("PFGRAD_VARIANT")) {
         for (int v = 0; v < kNumVariants; ++v)
             if (!std::strcmp(force, kVariants[v].tag) && n_max <= kVariants[v].NT * kVariants[v].PPT &&
-                lds_bytes(model, dtype, kVariants[v], n_max) <= kLdsLimit)
+                lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
                 return v;
     }
     for (int v = 0; v < 4; ++v) {
-        if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, kVariants[v], n_max) <= kLdsLimit)
+        if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
             return v;
     }
     return -1;
@@ -97,7 +100,7 @@ int pick_variant(int model, int dtype, int n_max) {
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, PP>(n_max);
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
     if (lds > 64 * 1024) {
         PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -149,7 +152,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
-    int v = pick_variant(model, dtype, n_max);
+    int v = pick_variant(model, dtype, rng, n_max);
     if (v < 0)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
@@ -180,8 +183,9 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
     pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A12u}, (uint32_t)seed, (uint32_t)(seed >> 32));
     const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps);
     double nz[4];
-    pfg::normal_pair(r0.x, r0.y, nz[0], nz[1]);
-    pfg::normal_pair(r1.x, r1.y, nz[2], nz[3]);
+    const pfg::Math<double, false> mth = {};
+    mth.normal_pair(r0.x, r0.y, nz[0], nz[1]);
+    mth.normal_pair(r1.x, r1.y, nz[2], nz[3]);
     if (model == PFG_MODEL_SVM || model == PFG_MODEL_LGSSM) {
         const bool lg = model == PFG_MODEL_LGSSM;
         double A = th[0], C = lg ? th[1] : 1.0, LQ = th[lg ? 2 : 1], LR = th[lg ? 3 : 2];
@@ -283,13 +287,13 @@ int pfg_synchronize(pfg_ctx *ctx) {
 }
 
 int64_t pfg_scratch_bytes(int model, int dtype, int N) {
-    if (pick_variant(model, dtype, N) >= 0) return 0;
+    if (pick_variant(model, dtype, PFG_RNG_DEVICE, N) >= 0) return 0;
     return -1;   // large-N variant not built yet
 }
 
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max) {
     (void)kernel; (void)rng;
-    int v = pick_variant(model, dtype, n_max);
+    int v = pick_variant(model, dtype, rng, n_max);
     return v < 0 ? "none" : kVariants[v].tag;
 }
 
@@ -375,7 +379,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
-    if (pick_variant(model, dtype, n_max) < 0)
+    if (pick_variant(model, dtype, rng, n_max) < 0)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
 

@@ -38,7 +38,10 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_struct_size(99) == -1
     assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4"
     assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
-    assert lib.pfg_variant_name(0, 0, 0, 1, 4000) == b"wg1024x4"
+    assert lib.pfg_variant_name(0, 0, 0, 1, 1500) == b"wg1024x4"
+    assert lib.pfg_variant_name(0, 0, 0, 1, 4000) == b"wg1024x4s"     # fp64 N=4000: single LDS buffer
+    assert lib.pfg_variant_name(0, 0, 1, 1, 4000) == b"wg1024x4"      # f32 state: ping-pong still fits
+    assert lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"none"          # GARCH fp64 N=4000: not LDS-resident
 
 
 def test_no_cpu_fallback_without_gpu():
