@@ -408,6 +408,8 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
 // (larger N fits in 160 KiB) at the price of a 4th barrier and of holding all gathered
 // parents in registers across it.
 // ------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
+
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;
     static constexpr int RED = PPT * NW + NW + PFG_MAX_STAT * NW + 8;  // doubles of scratch
@@ -418,7 +420,7 @@ template <int NT, int PPT> struct RegLayout {
 template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
-    size_t NC = PP ? (size_t)NT * PPT : NL;
+    size_t NC = PP ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // PP: padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, PP>();
 }
@@ -446,7 +448,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     const double *__restrict__ const zv = P.z;
 
     constexpr bool TAB = PP;            // table math + sentinel-padded cdf ride with ping-pong
-    const int NC = PP ? NT * PPT : NL;
+    // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
+    // binary search probes at power-of-two strides, which would otherwise all hit one LDS bank
+    // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).
+    const int NC = PP ? NT * PPT + NT * PPT / 32 : NL;
     double *cdf = reinterpret_cast<double *>(smem);
     REAL *buf0 = reinterpret_cast<REAL *>(cdf + NC);
     const size_t bufsz = (size_t)(NS + H) * NL;
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     if (PP) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (k * NT + tid >= N) cdf[k * NT + tid] = 2.0;      // sentinel: never <= u
+            if (k * NT + tid >= N) cdf[cdf_phys(k * NT + tid)] = 2.0;      // sentinel: never <= u
     }
     __syncthreads();
 
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         const bool use_stat = inside && (stat != PFG_STAT_NONE);
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (valid[k]) cdf[k * NT + tid] = cs[k] * invW;
+            if (valid[k]) cdf[PP ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
         __syncthreads();                                                        // barrier 3
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
@@ -655,12 +660,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = 0;
         if (PP) {
-            // sentinel-padded cdf: log2(NT*PPT) fixed probes, offsets fold into the ds_read
+            // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
+            // fold into the ds_read immediates; logical index recovered once at the end
 #pragma unroll
             for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                const int adv = step + (step >> 5);
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + step - 1] <= uu[k]) ? step : 0;
+                for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + probe] <= uu[k]) ? adv : 0;
             }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 8192)
         } else {
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
 #pragma unroll
@@ -677,8 +687,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
             // near-tie margin: how close u came to flipping an ancestor index
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const double hi = cdf[anc[k]] - uu[k];
-                const double lo = anc[k] > 0 ? uu[k] - cdf[anc[k] - 1] : 1.0;
+                const double hi = cdf[PP ? cdf_phys(anc[k]) : anc[k]] - uu[k];
+                const double lo = anc[k] > 0 ? uu[k] - cdf[PP ? cdf_phys(anc[k] - 1) : anc[k] - 1] : 1.0;
                 const double mg = hi < lo ? hi : lo;
                 tie = (valid[k] && mg < tie) ? mg : tie;
             }

@@ -40,7 +40,7 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
     assert lib.pfg_variant_name(0, 0, 0, 1, 1500) == b"wg1024x4"
     assert lib.pfg_variant_name(0, 0, 0, 1, 4000) == b"wg1024x4s"     # fp64 N=4000: single LDS buffer
-    assert lib.pfg_variant_name(0, 0, 1, 1, 4000) == b"wg1024x4"      # f32 state: ping-pong still fits
+    assert lib.pfg_variant_name(0, 0, 1, 1, 3500) == b"wg1024x4"      # f32 state: ping-pong fits further
     assert lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"none"          # GARCH fp64 N=4000: not LDS-resident
 
 
