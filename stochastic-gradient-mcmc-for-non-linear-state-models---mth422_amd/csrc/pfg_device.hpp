@@ -21,6 +21,13 @@ constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
 // row_bcast:15 / row_bcast:31 across rows (gfx9 cross-lane modes; no LDS traffic).
 // A lane whose DPP source does not exist keeps `old`, the operation's identity.
 // ------------------------------------------------------------------------------------
+// in-row shift with bound_ctrl: lanes without a source read 0 (no preset of the destination)
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr0_f64(double v) {
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
     int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
@@ -41,10 +48,10 @@ __device__ __forceinline__ float bcast_lane63(float v) {
 
 // inclusive prefix sum over the wave; lane 63 ends with the wave total
 __device__ __forceinline__ double wave_incl_scan(double v) {
-    v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
-    v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
-    v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
-    v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8
+    v += dpp_shr0_f64<0x111>(v);        // row_shr:1
+    v += dpp_shr0_f64<0x112>(v);        // row_shr:2
+    v += dpp_shr0_f64<0x114>(v);        // row_shr:4
+    v += dpp_shr0_f64<0x118>(v);        // row_shr:8
     v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1,3
     v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2,3
     return v;
@@ -57,6 +64,14 @@ __device__ __forceinline__ double wave_max(double v) {
     PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
 #undef PFG_MAX_STEP
     return bcast_lane63(v);
+}
+// Upper bound of the wave's maximum, reduced in f32 (v_max_f32 takes DPP operands directly:
+// 6 instructions instead of ~50 for f64).  The shift used by log_normalize only has to be
+// within a few ulp(f32) of the true maximum: exp(lw - m) and m + log(W/N) are invariant to it
+// up to rounding.
+__device__ __forceinline__ float max_shift_f32(double v) {
+    float f = (float)v;                                  // round to nearest
+    return f;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #define PFG_MAX_STEP(CTRL, RM) { float o = dpp_f32<CTRL, RM>(v, v); v = o > v ? o : v; }
@@ -459,6 +474,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
     double *red_scan = red;                 // [PPT*NW]
     double *red_max = red + PPT * NW;       // [NW]
+    float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;           // [H*NW]
     double *tabmem = red + RegLayout<NT, PPT>::RED;
 
@@ -559,17 +575,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
 
     for (int t = 0; t <= T; ++t) {
         // ---- (A) block max of the current log weights  (log_normalize, pf.py:374-377) ----
-        REAL ml = lw[0];
+        float ml = (float)lw[0];
 #pragma unroll
-        for (int k = 1; k < PPT; ++k) ml = lw[k] > ml ? lw[k] : ml;
+        for (int k = 1; k < PPT; ++k) ml = fmaxf(ml, (float)lw[k]);
         ml = wave_max(ml);
-        if (lane == 0) red_max[wave] = (double)ml;
+        if (lane == 0) red_maxf[wave] = ml;
         __syncthreads();                                                        // barrier 1
         {
-            double mm = red_max[0];
+            float mm = red_maxf[0];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) mm = red_max[w] > mm ? red_max[w] : mm;
-            m = mm;
+            for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
+            m = (double)mm;      // f32-rounded max: a valid shift for log_normalize (see wave_max)
         }
         // ---- (B) unnormalised weights, (C) prefix scan + weighted statistic sums --------
         const bool needS = needS_every || (t == T);
@@ -608,7 +624,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
             }
         }
         __syncthreads();                                                        // barrier 2
-        {
+        if (PPT * NW <= 16) {
+            // lane j < PPT*NW holds total j; exclusive prefix by a 16-lane DPP scan; each thread
+            // picks its PPT offsets and the grand total with v_readlane (uniform indices)
+            double tot = (lane < PPT * NW) ? red_scan[lane] : 0.0;
+            double inc = tot;
+            inc += dpp_shr0_f64<0x111>(inc);
+            inc += dpp_shr0_f64<0x112>(inc);
+            inc += dpp_shr0_f64<0x114>(inc);
+            inc += dpp_shr0_f64<0x118>(inc);
+            const double exc = inc - tot;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int j = k * NW + wave;
+                cs[k] += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), j),
+                                          __builtin_amdgcn_readlane(__double2loint(exc), j));
+            }
+            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), PPT * NW - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(inc), PPT * NW - 1));
+        } else {
             double run = 0.0;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -649,6 +683,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         const bool inside = (t >= t1) && (t < tL);
         const double wt = (inside && wv) ? wv[t - t1] : 1.0;
         const bool use_stat = inside && (stat != PFG_STAT_NONE);
+        const bool plain = !needS_every;                 // not filter and lambda == 1
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
             if (valid[k]) cdf[PP ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
@@ -710,12 +745,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
                 REAL xn[NS], add[H], lwn;
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
                 lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
+                if (plain) {
+                    // Poyiadjis O(N), lambda = 1: 1*s[a] + 0*S + w_t h = s[a] + w_t h exactly
+                    if (use_stat) {
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
-                    // pf.py:175-179 / :78-80
-                    const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
-                    sp[k][h] = is_filter ? a : sm;
+                        for (int h = 0; h < H; ++h) sp[k][h] = sp[k][h] + add[h] * (REAL)wt;
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
+                        // pf.py:175-179 / :78-80
+                        const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
+                        sp[k][h] = is_filter ? a : sm;
+                    }
                 }
                 if (valid[k]) {
                     const int i = k * NT + tid;
