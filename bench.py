@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains-per-gpu", type=int, default=512)
+    ap.add_argument("--chains-per-gpu", type=int, default=3072)
     ap.add_argument("--model", default="svm", choices=["svm", "garch"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -424,6 +424,9 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
 // parents in registers across it.
 // ------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
+// FAST layout = LDS math tables + sentinel-padded, bank-conflict-free cdf with an unrolled search.
+// Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
+__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 256; }
 
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;
@@ -435,13 +438,24 @@ template <int NT, int PPT> struct RegLayout {
 template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
-    size_t NC = PP ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // PP: padded 33/32 (see cdf_phys)
+    constexpr bool FAST = fast_layout(NT, PP);
+    size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
-           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, PP>();
+           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>();
+}
+
+// waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
+// 256x4 fp64: ping-pong state is 80 KB/workgroup -> 2 workgroups (2 waves/SIMD); the single
+// buffer is 50 KB -> 3, which is worth a few spilled registers (measured +15 %).
+__host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP) {
+    return (NT >= 512 || PPT == 1) ? 4 : ((PP && real == 8) ? 2 : 3);
+}
+__host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP) {
+    return (NT == 256 && PPT == 4 && !PP) ? 3 : 1;
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT >= 4096 || NT >= 1024) ? 4 : 2))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NW = NT / WAVE;
@@ -462,11 +476,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     const double *__restrict__ const uv = P.u;
     const double *__restrict__ const zv = P.z;
 
-    constexpr bool TAB = PP;            // table math + sentinel-padded cdf ride with ping-pong
+    constexpr bool FAST = fast_layout(NT, PP);
+    constexpr bool TAB = FAST;
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
     // binary search probes at power-of-two strides, which would otherwise all hit one LDS bank
     // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).
-    const int NC = PP ? NT * PPT + NT * PPT / 32 : NL;
+    const int NC = FAST ? NT * PPT + NT * PPT / 32 : NL;
     double *cdf = reinterpret_cast<double *>(smem);
     REAL *buf0 = reinterpret_cast<REAL *>(cdf + NC);
     const size_t bufsz = (size_t)(NS + H) * NL;
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
     mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
     mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
     if (tab_bytes<REAL, RNG, TAB>() > 0) tab_fill(tabmem, RNG == PFG_RNG_DEVICE, tid, NT);
-    if (PP) {
+    if (FAST) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
             if (k * NT + tid >= N) cdf[cdf_phys(k * NT + tid)] = 2.0;      // sentinel: never <= u
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         const bool plain = !needS_every;                 // not filter and lambda == 1
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (valid[k]) cdf[PP ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
+            if (valid[k]) cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
         __syncthreads();                                                        // barrier 3
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
         int anc[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = 0;
-        if (PP) {
+        if (FAST) {
             // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
             // fold into the ds_read immediates; logical index recovered once at the end
 #pragma unroll
@@ -722,8 +737,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, (NT * PPT
             // near-tie margin: how close u came to flipping an ancestor index
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const double hi = cdf[PP ? cdf_phys(anc[k]) : anc[k]] - uu[k];
-                const double lo = anc[k] > 0 ? uu[k] - cdf[PP ? cdf_phys(anc[k] - 1) : anc[k] - 1] : 1.0;
+                const double hi = cdf[FAST ? cdf_phys(anc[k]) : anc[k]] - uu[k];
+                const double lo = anc[k] > 0 ? uu[k] - cdf[FAST ? cdf_phys(anc[k] - 1) : anc[k] - 1] : 1.0;
                 const double mg = hi < lo ? hi : lo;
                 tie = (valid[k] && mg < tie) ? mg : tie;
             }

@@ -74,9 +74,10 @@ int theta_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
     size_t rs = dtype == PFG_F64 ? 8 : 4;
     size_t NL = (size_t)(N + 63) / 64 * 64;
-    size_t NC = v.pp ? (size_t)v.NT * v.PPT + (size_t)v.NT * v.PPT / 32 : NL;
+    const bool fast = pfg::fast_layout(v.NT, v.pp);
+    size_t NC = fast ? (size_t)v.NT * v.PPT + (size_t)v.NT * v.PPT / 32 : NL;
     size_t red = (size_t)v.PPT * (v.NT / 64) + (v.NT / 64) + (size_t)PFG_MAX_STAT * (v.NT / 64) + 8;
-    size_t tab = (v.pp && dtype == PFG_F64)
+    size_t tab = (fast && dtype == PFG_F64)
                      ? 8 * (size_t)(pfg::TAB_DOUBLES_EXP + (rng == PFG_RNG_DEVICE ? pfg::TAB_DOUBLES_RNG : 0)) : 0;
     return NC * 8 + (v.pp ? 2 : 1) * NL * (state_dim(model) + stat_dim(model)) * rs + red * 8 + tab;
 }
@@ -90,7 +91,12 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
                 lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
                 return v;
     }
-    for (int v = 0; v < 4; ++v) {
+    // preference order: fp64 N<=1024 runs best on the single-buffer 256x4 variant at 3
+    // workgroups per CU; f32 on ping-pong
+    const int order_f64[] = {0, 6, 1, 2, 3}, order_f32[] = {0, 1, 6, 2, 3};
+    const int *order = dtype == PFG_F64 ? order_f64 : order_f32;
+    for (int oi = 0; oi < 5; ++oi) {
+        const int v = order[oi];
         if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
             return v;
     }

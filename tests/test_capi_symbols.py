@@ -36,7 +36,7 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_version() == 100
     assert lib.pfg_struct_size(2) == _capi.DEV_PROBLEM_DTYPE.itemsize == 224
     assert lib.pfg_struct_size(99) == -1
-    assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4"
+    assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4s"
     assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
     assert lib.pfg_variant_name(0, 0, 0, 1, 1500) == b"wg1024x4"
     assert lib.pfg_variant_name(0, 0, 0, 1, 4000) == b"wg1024x4s"     # fp64 N=4000: single LDS buffer
