@@ -149,9 +149,10 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
  * n_max = the largest N in the batch (selects the kernel variant). */
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
-/* bytes of per-problem scratch the large-N variant needs for (model, dtype, N); 0 if the
- * LDS-resident variant serves this size */
-int64_t pfg_scratch_bytes(int model, int dtype, int N);
+/* bytes of per-problem HBM scratch (pfg_dev_problem.scratch, 256-byte aligned) the large-N
+ * kernel needs for (model, dtype, rng, N); 0 when an LDS-resident variant serves this size,
+ * -1 when N is above the supported maximum (16384) */
+int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N);
 /* name of the kernel variant pfg_launch_device would pick (for profiles / logs) */
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max);
 int pfg_synchronize(pfg_ctx *ctx);

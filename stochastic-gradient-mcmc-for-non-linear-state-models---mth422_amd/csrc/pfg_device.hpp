@@ -846,4 +846,320 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Large-N kernel: one 1024-thread workgroup per window, any N <= MEM_MAX_N.  Only the CDF
+// (padded, sentinel-filled up to the next power of two) and the math tables live in LDS;
+// particles, statistics and log-weights live in a per-window HBM scratch that stays
+// L2-resident (N = 10000 fp64 SVM: 2 x 320 KB ping-pong + 80 KB), every access by the owning
+// thread coalesced over the particle axis, only the parent gather random.  The timestep is
+// the same phase sequence as pf_reg_kernel with rolled loops over chunks of 1024 particles.
+//   scratch (REAL): lw[N] | buf0 {x[NS][N], stats[H][N]} | buf1 {...}
+// ------------------------------------------------------------------------------------
+constexpr int MEM_NT = 1024;
+constexpr int MEM_NW = MEM_NT / WAVE;
+constexpr int MEM_MAX_N = 16384;
+constexpr int MEM_MAX_CHUNKS = MEM_MAX_N / MEM_NT;
+
+__host__ __device__ inline int mem_np2(int N) { int p = 64; while (p < N) p <<= 1; return p; }
+
+template <int MODEL, typename REAL>
+__host__ __device__ inline size_t mem_kernel_scratch_bytes(int N) {
+    return (size_t)N * (1 + 2 * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H)) * sizeof(REAL);
+}
+template <typename REAL, int RNG>
+__host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
+    const size_t np2 = (size_t)mem_np2(N);
+    return (np2 + np2 / 32) * 8 + (size_t)(2 * MEM_MAX_CHUNKS * MEM_NW + MEM_NW + PFG_MAX_STAT * MEM_NW + 8) * 8 +
+           tab_bytes<REAL, RNG, true>();
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+__global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *__restrict__ probs) {
+    constexpr int NS = ModelDims<MODEL>::NS;
+    constexpr int H = ModelDims<MODEL>::H;
+    constexpr int NT = MEM_NT, NW = MEM_NW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const pfg_dev_problem &P = probs[blockIdx.x];
+    const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int nchunk = (N + NT - 1) / NT;
+    const int np2 = mem_np2(N);
+    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = P.stat;
+    const double lam_d = is_filter ? 0.0 : P.lambduh;
+    const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
+    const bool needS_every = is_filter || (lam_d != 1.0);
+    const double *__restrict__ const yv = P.y;
+    const double *__restrict__ const wv = P.weights;
+    const double *__restrict__ const uv = P.u;
+    const double *__restrict__ const zv = P.z;
+
+    double *cdf = reinterpret_cast<double *>(smem);                 // [np2 + np2/32] physical
+    double *red_scan = cdf + (np2 + np2 / 32);                      // [MAX_CHUNKS*NW] wave totals
+    double *red_off = red_scan + MEM_MAX_CHUNKS * NW;               // [MAX_CHUNKS*NW] exclusive offsets
+    double *red_max = red_off + MEM_MAX_CHUNKS * NW;                // [NW]
+    float *red_maxf = reinterpret_cast<float *>(red_max);
+    double *red_S = red_max + NW;                                   // [H*NW]
+    double *red_W = red_S + PFG_MAX_STAT * NW;                      // [1] grand total (+ spare)
+    double *tabmem = red_W + 8;
+
+    REAL *lwg = reinterpret_cast<REAL *>(P.scratch);                // [N]
+    REAL *cur = lwg + N;                                            // {x[NS][N], s[H][N]}
+    REAL *nxt = cur + (size_t)(NS + H) * N;
+
+    Math<REAL, true> mth;
+    mth.t.e2 = tabmem;
+    mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
+    mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
+    if (tab_bytes<REAL, RNG, true>() > 0) tab_fill(tabmem, RNG == PFG_RNG_DEVICE, tid, NT);
+    for (int i = N + tid; i < np2; i += NT) cdf[cdf_phys(i)] = 2.0;  // sentinel: never <= u
+
+    const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
+    LaneRng rng = {};
+    if (RNG == PFG_RNG_DEVICE)
+        rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
+
+    // ---- x0 or warm start ---------------------------------------------------------------
+    {
+        double pv = P.prior_var;
+        if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
+            pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
+        const double sd = sqrt(pv);
+        for (int i = tid; i < N; i += NT) {
+            REAL x[NS], s[H], l0 = (REAL)0;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
+#pragma unroll
+            for (int h = 0; h < H; ++h) s[h] = (REAL)0;
+            if (P.init_x) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) x[d] = (REAL)P.init_x[(size_t)i * NS + d];
+                l0 = (REAL)P.init_logw[i];
+                if (P.init_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) s[h] = (REAL)P.init_stats[(size_t)i * H + h];
+                }
+            } else {
+                double z;
+                if (RNG == PFG_RNG_REPLAY) z = P.z0[i];
+                else { REAL a, b; mth.normal_pair(rng.next(), rng.next(), a, b); z = (double)a; }
+                x[0] = (REAL)(P.prior_mean + sd * z);
+            }
+            lwg[i] = l0;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) cur[(size_t)d * N + i] = x[d];
+#pragma unroll
+            for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * N + i] = s[h];
+            if (P.trace_x) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
+                P.trace_logw[i] = (double)l0;
+                if (P.trace_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) P.trace_stats[(size_t)i * H + h] = (double)s[h];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    double ll = 0.0, wt_prev = 1.0, tie = 1.0;
+    double filt[H], S[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { filt[h] = 0.0; S[h] = 0.0; }
+    double m = 0.0, W = (double)N;
+
+    for (int t = 0; t <= T; ++t) {
+        // ---- (A) max of the log weights (f32-rounded shift, see wave_max) -------------------
+        float ml = -INFINITY;
+        for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
+        ml = wave_max(ml);
+        if (lane == 0) red_maxf[wave] = ml;
+        __syncthreads();                                                        // barrier 1
+        {
+            float mm = red_maxf[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
+            m = (double)mm;
+        }
+        // ---- (B,C) weights, per-chunk wave scans (unnormalised, wave-local) into the CDF -----
+        const bool needS = needS_every || (t == T);
+        {
+            double part[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) part[h] = 0.0;
+            for (int j = 0; j < nchunk; ++j) {
+                const int i = j * NT + tid;
+                const bool v = i < N;
+                const int ii = v ? i : N - 1;
+                double p = (double)mth.exp((REAL)(lwg[ii] - (REAL)m));
+                p = v ? p : 0.0;
+                if (needS) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) part[h] += (double)cur[(size_t)(NS + h) * N + ii] * p;
+                }
+                const double inc = wave_incl_scan(p);
+                if (v) cdf[cdf_phys(i)] = inc;
+                if (lane == WAVE - 1) red_scan[j * NW + wave] = inc;
+            }
+            if (needS) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double tot = wave_sum(part[h]);
+                    if (lane == 0) red_S[h * NW + wave] = tot;
+                }
+            }
+        }
+        __syncthreads();                                                        // barrier 2
+        if (wave == 0) {
+            // exclusive offsets of the nchunk*NW wave totals (<= 256): 4 per lane + one wave scan
+            const int ntot = nchunk * NW;
+            double v4[4], loc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane * 4 + q;
+                v4[q] = idx < ntot ? red_scan[idx] : 0.0;
+                loc += v4[q];
+            }
+            const double inc = wave_incl_scan(loc);
+            double run = inc - loc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane * 4 + q;
+                if (idx < ntot) red_off[idx] = run;
+                run += v4[q];
+            }
+            if (lane == WAVE - 1) red_W[0] = inc;
+        }
+        __syncthreads();                                                        // barrier 2b
+        W = red_W[0];
+        const double invW = 1.0 / W;
+        if (needS) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double acc = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc += red_S[h * NW + w];
+                S[h] = acc * invW;
+            }
+        }
+        if (wave == 0) {
+            if (t > 0 && (t - 1) >= t1 && (t - 1) < tL) ll += wt_prev * (m + log(W / (double)N));
+            if (P.trace_ll && tid == 0) P.trace_ll[t] = ll;
+        }
+        if (is_filter && t > 0) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) filt[h] += S[h];
+        }
+        if (t == T) break;
+
+        // ---- (D) normalise the CDF in place (own entries) -------------------------------------
+        for (int j = 0; j < nchunk; ++j) {
+            const int i = j * NT + tid;
+            if (i < N) {
+                const int pi = cdf_phys(i);
+                cdf[pi] = (cdf[pi] + red_off[j * NW + wave]) * invW;
+            }
+        }
+        __syncthreads();                                                        // barrier 3
+
+        const double y_t = yv[t];
+        const bool inside = (t >= t1) && (t < tL);
+        const double wt = (inside && wv) ? wv[t - t1] : 1.0;
+        const bool use_stat = inside && (stat != PFG_STAT_NONE);
+        // ---- (E..H) per particle: ancestor search, gather parent (HBM/L2), propose, publish ---
+        auto sweep = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            for (int j = 0; j < nchunk; ++j) {
+                const int i = j * NT + tid;
+                const bool v = i < N;
+                const int ii = v ? i : N - 1;
+                double u;
+                REAL z;
+                if (RNG == PFG_RNG_REPLAY) { u = uv[(size_t)t * N + ii]; z = (REAL)zv[(size_t)t * N + ii]; }
+                else { REAL zb; u = u01_32(rng.next()); mth.normal_pair(rng.next(), rng.next(), z, zb); }
+                int pos = 0;
+                for (int step = np2 >> 1; step >= 1; step >>= 1) {
+                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                    pos += (cdf[pos + probe] <= u) ? step + (step >> 5) : 0;
+                }
+                int a = pos - ((pos * 993) >> 15) ;
+                if (np2 > 8192) a = pos - pos / 33;          // exact mul-shift only below 8192
+                a = a < N - 1 ? a : N - 1;
+                if (RNG == PFG_RNG_REPLAY && v) {
+                    const double hi = cdf[cdf_phys(a)] - u;
+                    const double lo = a > 0 ? u - cdf[cdf_phys(a - 1)] : 1.0;
+                    const double mg = hi < lo ? hi : lo;
+                    tie = mg < tie ? mg : tie;
+                }
+                REAL xp[NS], sp[H], xn[NS], add[H], lwn;
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * N + a];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sp[h] = cur[(size_t)(NS + h) * N + a];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z, xn, lwn, add);
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const REAL av = use_stat ? add[h] * (REAL)wt : (REAL)0;
+                    const REAL sm = (lam * sp[h] + oml * (REAL)S[h]) + av;      // pf.py:175-179 / :78-80
+                    sp[h] = is_filter ? av : sm;
+                }
+                if (v) {
+                    lwg[i] = lwn;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * N + i] = xn[d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * N + i] = sp[h];
+                    if (P.trace_x) {
+                        const size_t row = (size_t)(t + 1) * N + i;
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)xn[d];
+                        P.trace_logw[row] = (double)lwn;
+                        if (P.trace_stats && !is_filter) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)sp[h];
+                        }
+                    }
+                }
+            }
+        };
+        if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+        else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+        { REAL *tmp = cur; cur = nxt; nxt = tmp; }
+        wt_prev = wt;
+        // children (global stores) must be visible to next step's gathers: barrier 1 of the next
+        // iteration orders them (__syncthreads = waitcnt + workgroup barrier, same CU / same L1)
+    }
+
+    // ---- outputs --------------------------------------------------------------------------
+    if (RNG == PFG_RNG_REPLAY && P.out) {
+        tie = -wave_max(-tie);
+        if (lane == 0) red_max[wave] = tie;
+        __syncthreads();
+        tie = red_max[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
+    }
+    if (tid == 0 && P.out) {
+#pragma unroll
+        for (int h = 0; h < PFG_MAX_STAT; ++h) P.out[h] = 0.0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) P.out[h] = is_filter ? filt[h] : S[h];
+        P.out[4] = ll; P.out[5] = W; P.out[6] = m; P.out[7] = tie;
+    }
+    if (P.final_x) {
+        for (int i = tid; i < N; i += NT) {
+#pragma unroll
+            for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * N + i];
+            if (P.final_logw) P.final_logw[i] = (double)lwg[i];
+            if (P.final_stats && !is_filter) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * N + i];
+            }
+        }
+    }
+}
+
 }  // namespace pfg

@@ -37,7 +37,7 @@ struct pfg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    Arena in, out, desc;
+    Arena in, out, desc, scratch;
     std::vector<double> h_in, h_out;
     std::vector<pfg_dev_problem> h_desc;
 };
@@ -66,6 +66,7 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               {256, 4, false, "wg256x4s"} };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr size_t kLdsLimit = 160 * 1024;
+constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
 
 int state_dim(int model) { return model == PFG_MODEL_GARCH ? 2 : 1; }
 int stat_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
@@ -86,6 +87,7 @@ size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
 // variant (tuning / tests) when it can hold n_max.
 int pick_variant(int model, int dtype, int rng, int n_max) {
     if (const char *force = std::getenv("PFGRAD_VARIANT")) {
+        if (!std::strcmp(force, "mem1024") && n_max <= pfg::MEM_MAX_N) return kVariantMem;
         for (int v = 0; v < kNumVariants; ++v)
             if (!std::strcmp(force, kVariants[v].tag) && n_max <= kVariants[v].NT * kVariants[v].PPT &&
                 lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
@@ -100,7 +102,12 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
         if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
             return v;
     }
+    if (n_max <= pfg::MEM_MAX_N) return kVariantMem;
     return -1;
+}
+
+size_t scratch_bytes(int model, int dtype, int N) {
+    return (size_t)N * (1 + 2 * (state_dim(model) + stat_dim(model))) * (dtype == PFG_F64 ? 8 : 4);
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
@@ -130,9 +137,31 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
 }
 
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
+    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+
 template <int MODEL, int KERNEL>
 int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
               hipStream_t st) {
+    if (v == kVariantMem) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_mem<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_mem<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+    }
     if (dtype == PFG_F64) {
         if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
         return launch_v<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
@@ -159,9 +188,9 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
     int v = pick_variant(model, dtype, rng, n_max);
-    if (v < 0)
+    if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
-                    "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
+                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
     if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
     if (model == PFG_MODEL_GARCH) {
         if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
@@ -280,7 +309,7 @@ void pfg_destroy(pfg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    ctx->in.release(); ctx->out.release(); ctx->desc.release();
+    ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release();
     delete ctx;
 }
 
@@ -292,15 +321,18 @@ int pfg_synchronize(pfg_ctx *ctx) {
     return PFG_OK;
 }
 
-int64_t pfg_scratch_bytes(int model, int dtype, int N) {
-    if (pick_variant(model, dtype, PFG_RNG_DEVICE, N) >= 0) return 0;
-    return -1;   // large-N variant not built yet
+int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N) {
+    if (model < 0 || model > 2 || N < 1) return -1;
+    const int v = pick_variant(model, dtype, rng, N);
+    if (v >= 0) return 0;
+    if (v == kVariantMem) return (int64_t)((scratch_bytes(model, dtype, N) + 255) / 256 * 256);
+    return -1;
 }
 
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max) {
     (void)kernel; (void)rng;
     int v = pick_variant(model, dtype, rng, n_max);
-    return v < 0 ? "none" : kVariants[v].tag;
+    return v == kVariantMem ? "mem1024" : (v < 0 ? "none" : kVariants[v].tag);
 }
 
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
@@ -385,14 +417,19 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
-    if (pick_variant(model, dtype, rng, n_max) < 0)
+    const int variant = pick_variant(model, dtype, rng, n_max);
+    if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
-                    "N = " + std::to_string(n_max) + " exceeds the LDS-resident variants for this model/dtype");
+                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
+    size_t n_scratch = 0;                  // bytes; every window of the batch gets n_max-sized state
+    const size_t scratch_each = (scratch_bytes(model, dtype, n_max) + 255) / 256 * 256;
+    if (variant == kVariantMem) n_scratch = scratch_each * (size_t)B;
 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     PFG_HIP(ctx, ctx->in.ensure(n_in * 8));
     PFG_HIP(ctx, ctx->out.ensure(n_out * 8));
     PFG_HIP(ctx, ctx->desc.ensure((size_t)B * sizeof(pfg_dev_problem)));
+    if (n_scratch) PFG_HIP(ctx, ctx->scratch.ensure(n_scratch));
     try {
         ctx->h_in.resize(n_in);
         ctx->h_out.resize(n_out);
@@ -451,7 +488,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.trace_stats = take(r.trace_stats != nullptr, (size_t)(q.T + 1) * q.N * H);
         d.trace_ll = take(r.trace_ll != nullptr, (size_t)q.T + 1);
         d.step_ctr = nullptr;
-        d.scratch = nullptr;
+        d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
+                              : nullptr;
         d.prior_mean = q.prior_mean; d.prior_var = q.prior_var; d.lambduh = q.lambduh;
         d.seed = q.seed; d.stream = q.stream;
         d.T = q.T; d.t1 = q.t1; d.tL = tL; d.N = q.N;

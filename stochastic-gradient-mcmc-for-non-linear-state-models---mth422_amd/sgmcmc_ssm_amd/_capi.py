@@ -134,7 +134,7 @@ def load_library():
     lib.pfg_launch_device.restype = C.c_int
     lib.pfg_ctx_stream.argtypes = [C.c_void_p]
     lib.pfg_ctx_stream.restype = C.c_void_p
-    lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
     lib.pfg_variant_name.restype = C.c_char_p
@@ -290,6 +290,9 @@ class Context:
             float(epsilon), float(Tscale), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
             C.c_uint64(int(chain_offset)), C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
             C.c_void_p(int(stream_ptr))))
+
+    def scratch_bytes(self, model, dtype, rng, N):
+        return int(self.lib.pfg_scratch_bytes(MODEL[model], DTYPE[dtype], RNG[rng], int(N)))
 
     def variant_name(self, model, kernel, dtype, rng, n_max):
         return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()

@@ -142,6 +142,13 @@ class ChainEnsemble(object):
         d["smoother"], d["stat"] = _capi.SMOOTHER["nemeth"], _capi.STAT["score"]
         if model == "garch" and self.helper.default_forward_message is None:
             d["flags"] = _capi.FLAG_GARCH_STATIONARY_PRIOR
+        sb = self.ctx.scratch_bytes(model, dtype, "device", self.N)
+        if sb < 0:
+            raise ValueError("N = {0} is above the supported maximum".format(self.N))
+        self.scratch_dev = None
+        if sb > 0:       # large-N kernel: particle state lives in HBM (L2-resident), one slab per chain
+            self.scratch_dev = torch.empty(self.C * sb, dtype=torch.uint8, device=dev)
+            d["scratch"] = self.scratch_dev.data_ptr() + np.arange(self.C, dtype=np.uint64) * np.uint64(sb)
         self._host_rng = np.random.RandomState((self.seed * 7919 + self.chain_offset) % (2 ** 32))
         self._set_windows(first=True)
         self.desc_dev = torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)).to(dev)

@@ -74,8 +74,6 @@ def test_window_cases_f64(ctx, golden_window):
     g = golden_window
     n = 0
     for m in g.meta:
-        if m["N"] > 4096:
-            continue          # large-N variant: separate test
         q = _problem(m, g)
         o = ctx.run_batch([q], want_final=True)[0]
         key = m["key"]
@@ -92,7 +90,50 @@ def test_window_cases_f64(ctx, golden_window):
             np.testing.assert_allclose(o["x_t"], g.get(key, "x_t"), rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(o["log_weights"], g.get(key, "log_weights"), rtol=RTOL, atol=ATOL)
         n += 1
-    assert n >= 25
+    assert n >= 30
+
+
+@pytest.fixture
+def force_mem_kernel(monkeypatch):
+    """Route every launch to the large-N kernel (state in HBM scratch) whatever N is."""
+    monkeypatch.setenv("PFGRAD_VARIANT", "mem1024")
+
+
+def test_trace_cases_f64_large_n_kernel(ctx, golden_trace, force_mem_kernel):
+    """The large-N kernel on the fully traced reference cases (all models / smoothers)."""
+    test_trace_cases_f64(ctx, golden_trace)
+
+
+def test_window_cases_f64_large_n_kernel(ctx, golden_window, force_mem_kernel):
+    test_window_cases_f64(ctx, golden_window)
+
+
+def test_large_n_vs_oracle(ctx):
+    """N beyond the LDS-resident variants: GARCH fp64 N=4000 (112 B/particle), SVM N=10000
+    (BASELINE config 5 shape), LGSSM N=16384 (maximum), Nemeth and filter smoothers."""
+    rs = np.random.RandomState(77)
+    cases = [("garch", "optimal", [0.0, 2.0, 2.0, 1.8], 4000, 12, "nemeth", 1.0),
+             ("garch", "prior", [0.0, 2.0, 2.0, 1.8], 5000, 6, "nemeth", 0.9),
+             ("svm", "prior", [0.95, 1.4, 1.4], 10000, 24, "nemeth", 1.0),
+             ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 16384, 5, "nemeth", 0.95),
+             ("svm", "prior", [0.9, 1.2, 1.1], 9000, 8, "filter", 1.0)]
+    for model, kernel, theta, N, T, smoother, lam in cases:
+        y = rs.normal(size=T)
+        t1, tL = 1, T - 1
+        w = rs.uniform(1.0, 40.0, size=tL - t1)
+        z0, u, z = po.draw_streams(rs, N, T)
+        q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="replay", N=N,
+                 t1=t1, tL=tL, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w, theta=theta,
+                 z0=z0, u=u, z=z)
+        assert ctx.variant_name(model, kernel, "f64", "replay", N) == "mem1024"
+        o = ctx.run_batch([q], want_final=True)[0]
+        r = po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel, pf="filter" if smoother == "filter" else "nemeth",
+                         lambduh=lam, stat="score", t1=t1, tL=tL, weights=w, prior_mean=0.0, prior_var=1.5)
+        np.testing.assert_allclose(o["x_t"], r["x_t"], rtol=RTOL, atol=ATOL, err_msg=model)
+        np.testing.assert_allclose(o["log_weights"], r["log_weights"], rtol=RTOL, atol=ATOL)
+        ref = r["statistics"] if smoother == "filter" else r["mean_statistic"]
+        np.testing.assert_allclose(o["mean_stat"], ref, rtol=1e-8, atol=1e-8)
+        assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= 1e-8 * max(1.0, abs(r["loglikelihood_estimate"]))
 
 
 def test_batch_heterogeneous_vs_oracle(ctx):
