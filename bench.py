@@ -201,7 +201,7 @@ def main():
                              "GARCH synthetic T=1000 N=1000, SGLD buffered PF S=16 B=4, poyiadjis_N, optimal kernel"),
                 "chains_per_gpu": C,
                 "chains_total": C * world,
-                "rng": "philox (device)",
+                "rng": "device (xoshiro128++ per lane keyed by Philox4x32-10)",
                 "kernel_variant": ens.ctx.variant_name(args.model, cfg["kernel"], args.dtype, "philox", N_PART),
                 "parallelism": "independent chains, {0} GPU(s) x {1} chains, RCCL all_gather of samples".format(world, C),
             },

@@ -60,10 +60,7 @@ int fail(pfg_ctx *ctx, int code, const std::string &msg) {
 // ---- kernel variants ----------------------------------------------------------------
 // pp = ping-pong LDS state buffers (3 barriers/step); single buffer fits larger N (4 barriers).
 struct Variant { int NT, PPT; bool pp; const char *tag; };
-const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"},
-                              {1024, 4, true, "wg1024x4"}, {1024, 4, false, "wg1024x4s"},
-                              {512, 2, true, "wg512x2"}, {1024, 1, true, "wg1024x1"},
-                              {256, 4, false, "wg256x4s"} };
+const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"}, {256, 4, false, "wg256x4s"} };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
@@ -94,10 +91,11 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
                 return v;
     }
     // preference order: fp64 N<=1024 runs best on the single-buffer 256x4 variant at 3
-    // workgroups per CU; f32 on ping-pong
-    const int order_f64[] = {0, 6, 1, 2, 3}, order_f32[] = {0, 1, 6, 2, 3};
+    // workgroups per CU; f32 on ping-pong.  N > 1024 goes to the large-N kernel: 1024-thread
+    // register-resident variants spill at the 128-VGPR cap and measured 3-5x slower than it.
+    const int order_f64[] = {0, 2, 1}, order_f32[] = {0, 1, 2};
     const int *order = dtype == PFG_F64 ? order_f64 : order_f32;
-    for (int oi = 0; oi < 5; ++oi) {
+    for (int oi = 0; oi < 3; ++oi) {
         const int v = order[oi];
         if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
             return v;
@@ -128,11 +126,7 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
     switch (v) {
         case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
         case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
-        case 2: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, true>(ctx, n_max, B, dp, st);
-        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st);
-        case 4: return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, true>(ctx, n_max, B, dp, st);
-        case 5: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
-        case 6: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
+        case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
     }
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
 }
