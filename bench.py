@@ -124,15 +124,16 @@ def main():
         raise SystemExit("--gpus {0} but WORLD_SIZE={1}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # 1:1 on a full node; folds ranks when rehearsing on one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     p0, y, prior, cfg = make_workload(args.model)
     C = args.chains_per_gpu
     lo, _ = distributed.chain_range(rank, C)
     ens = ChainEnsemble(args.model, y, p0, num_chains=C, N=N_PART, pf="poyiadjis_N", kernel=cfg["kernel"],
                         epsilon=cfg["epsilon"], prior=prior, subsequence_length=cfg["S"],
-                        buffer_length=cfg["B"], dtype=args.dtype, seed=2024, chain_offset=lo, device=local_rank)
+                        buffer_length=cfg["B"], dtype=args.dtype, seed=2024, chain_offset=lo, device=dev_index)
 
     for _ in range(args.warmup):
         ens.step(1)

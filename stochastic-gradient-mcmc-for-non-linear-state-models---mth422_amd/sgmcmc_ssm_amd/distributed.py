@@ -20,9 +20,11 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
+            backend = os.environ.get("PFG_DIST_BACKEND")     # rehearsal override (e.g. gloo on one GPU)
+        if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
@@ -39,15 +41,20 @@ def gather_samples(local):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local.clone()
     local = local.contiguous()
+    dev = local.device
+    if dist.get_backend() == "gloo" and dev.type != "cpu":
+        local = local.cpu()                   # gloo rehearsal of a GPU job: stage through the host
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local)
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(dev)
 
 
 def max_over_ranks(value, device=None):
     """max of a python float over ranks (bench timing)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
