@@ -174,6 +174,13 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
                            uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr,
                            void *hip_stream);
 
+/* Inverse-multiquadric kernel Stein discrepancy of K points x[K][d] with score estimates
+ * g[K][d] (HOST pointers, d <= 8): sqrt(sum_{i,j} k0(x_i,x_j)) / K for
+ * k(x,y) = (c^2 + |x-y|^2)^(-beta) -- IMQ_KSD of sgmcmc_ssm/trace_metric_functions.py:20-81
+ * (the O(K^2) pass of the KSD evaluation, nonlinear_ssm_pf_experiment_scripts/svm/driver.py:906-1090). */
+int pfg_imq_ksd(pfg_ctx *ctx, int K, int d, const double *x, const double *g, double c, double beta,
+                double *ksd_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -622,20 +622,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
             cs[k] = wave_incl_scan(cs[k]);
             if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
         }
-        // this step's randomness (independent of the barrier: overlaps the wait)
+        // this step's randomness: REPLAY loads are issued here so that their latency overlaps the
+        // barrier; device draws happen right before their use (keeps register pressure down)
         double uu[PPT];
         REAL zz[PPT];
-        if (t < T) {
-            if (RNG == PFG_RNG_REPLAY) {
+        if (t < T && RNG == PFG_RNG_REPLAY) {
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    uu[k] = uv[(size_t)t * N + own[k]];
-                    zz[k] = (REAL)zv[(size_t)t * N + own[k]];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
-                draw_normals(zz);
+            for (int k = 0; k < PPT; ++k) {
+                uu[k] = uv[(size_t)t * N + own[k]];
+                zz[k] = (REAL)zv[(size_t)t * N + own[k]];
             }
         }
         __syncthreads();                                                        // barrier 2
@@ -706,6 +701,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
         // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
+        if (RNG != PFG_RNG_REPLAY) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
+        }
         int anc[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = 0;
@@ -755,6 +754,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
             }
             if (!PP) __syncthreads();                                           // barrier 4 (single buffer)
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 REAL xn[NS], add[H], lwn;

@@ -257,6 +257,35 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
 
 __global__ void bump_counter_kernel(uint64_t *ctr) { *ctr += 1; }
 
+// ---- IMQ kernel Stein discrepancy: all K^2 pairs, row i per workgroup-stride, f64 ----------
+constexpr int KSD_MAX_D = 8;
+__global__ __launch_bounds__(256) void imq_ksd_kernel(int K, int d, const double *__restrict__ x,
+                                                      const double *__restrict__ g, double c2, double beta,
+                                                      double *__restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = blockIdx.x; i < K; i += gridDim.x) {
+        double xi[KSD_MAX_D], gi[KSD_MAX_D];
+        for (int k = 0; k < d; ++k) { xi[k] = x[(size_t)i * d + k]; gi[k] = g[(size_t)i * d + k]; }
+        for (int j = threadIdx.x; j < K; j += blockDim.x) {
+            double diff2 = 0.0, gg = 0.0, g0d = 0.0, g1d = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double df = xi[k] - x[(size_t)j * d + k];
+                const double gj = g[(size_t)j * d + k];
+                diff2 += df * df; gg += gi[k] * gj; g0d += gi[k] * -df; g1d += gj * df;
+            }
+            const double base = diff2 + c2;
+            const double bb = pow(base, -beta);
+            const double coeff = -2.0 * beta * (bb / base);
+            acc += gg * bb + g0d * coeff + g1d * coeff + (-(double)d + 2.0 * (beta + 1.0) * diff2 / base) * coeff;
+        }
+    }
+    acc = pfg::wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -351,6 +380,32 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
                        *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr);
     if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);
     PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+int pfg_imq_ksd(pfg_ctx *ctx, int K, int d, const double *x, const double *g, double c, double beta,
+                double *ksd_out) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!x || !g || !ksd_out) return fail(ctx, PFG_ERR_INVALID, "pfg_imq_ksd: NULL argument");
+    if (K < 1 || d < 1 || d > KSD_MAX_D) return fail(ctx, PFG_ERR_INVALID, "pfg_imq_ksd: need K >= 1 and 1 <= d <= 8");
+    if (!(beta > 0.0 && beta < 1.0)) return fail(ctx, PFG_ERR_INVALID, "pfg_imq_ksd: beta must be in (0,1)");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)K * d;
+    const int nblk = K < 1024 ? K : 1024;
+    PFG_HIP(ctx, ctx->in.ensure(2 * n * 8));
+    PFG_HIP(ctx, ctx->out.ensure((size_t)nblk * 8));
+    double *dx = static_cast<double *>(ctx->in.ptr), *dg = dx + n;
+    PFG_HIP(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PFG_HIP(ctx, hipMemcpyAsync(dg, g, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(imq_ksd_kernel, dim3(nblk), dim3(256), 0, ctx->stream, K, d, dx, dg, c * c, beta,
+                       static_cast<double *>(ctx->out.ptr));
+    PFG_HIP(ctx, hipGetLastError());
+    try { ctx->h_out.resize(nblk); } catch (const std::bad_alloc &) { return fail(ctx, PFG_ERR_NOMEM, "out of host memory"); }
+    PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, (size_t)nblk * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int b = 0; b < nblk; ++b) tot += ctx->h_out[b];          // fixed order: reproducible
+    *ksd_out = std::sqrt(tot) / (double)K;
     return PFG_OK;
 }
 

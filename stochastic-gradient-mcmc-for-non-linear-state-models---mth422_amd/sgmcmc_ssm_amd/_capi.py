@@ -75,7 +75,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
-           "pfg_sgld_update_device")
+           "pfg_sgld_update_device", "pfg_imq_ksd")
 
 _lib = None
 
@@ -144,6 +144,8 @@ def load_library():
                                            C.POINTER(PriorHyper), C.c_double, C.c_double, C.c_uint64,
                                            C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pfg_sgld_update_device.restype = C.c_int
+    lib.pfg_imq_ksd.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp]
+    lib.pfg_imq_ksd.restype = C.c_int
     _lib = lib
     return lib
 
@@ -293,6 +295,15 @@ class Context:
 
     def scratch_bytes(self, model, dtype, rng, N):
         return int(self.lib.pfg_scratch_bytes(MODEL[model], DTYPE[dtype], RNG[rng], int(N)))
+
+    def imq_ksd(self, x, gradlogp, c=1.0, beta=0.5):
+        x, g = _as_f64(x), _as_f64(gradlogp)
+        if x.ndim != 2 or x.shape != g.shape:
+            raise ValueError("x and gradlogp dimensions do not match")
+        out = C.c_double()
+        self._check(self.lib.pfg_imq_ksd(self.handle, x.shape[0], x.shape[1], _ptr(x), _ptr(g), float(c),
+                                         float(beta), C.byref(out)))
+        return float(out.value)
 
     def variant_name(self, model, kernel, dtype, rng, n_max):
         return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()

@@ -276,8 +276,11 @@ class SGMCMCSampler(object):
                 for _ in range(minibatch_size)]
         elif len(buffer_dicts) != minibatch_size:
             raise ValueError("len(buffer_dicts != minibatch_size")
-        return [(self._window_problem(bd, observations, "score", **kwargs), minibatch_size)
-                for bd in buffer_dicts]
+        probs = [(self._window_problem(bd, observations, "score", **kwargs), minibatch_size)
+                 for bd in buffer_dicts]
+        for q, _ in probs:
+            q["_series_length"] = T          # host-side metadata (Seq rescaling); not sent to the device
+        return probs
 
     def _run_grad_problems(self, groups):
         """groups: list (one per series) of [(problem, minibatch_size)].  One launch for all
@@ -319,6 +322,54 @@ class SGMCMCSampler(object):
         if is_scaled:
             for var in grad:
                 grad[var] = grad[var] / T_total
+        return grad
+
+    def noisy_gradient_trace(self, parameters_list, is_scaled=True, **kwargs):
+        """noisy_gradient at every Parameters of a stored trace, ALL in one launch (one workgroup
+        per stored parameter x window).  Equivalent -- also in its np.random consumption -- to
+            for p in parameters_list: sampler.parameters = p; sampler.noisy_gradient(**kwargs)
+        which is the gradient loop of the KSD evaluation (svm/driver.py:1006-1027).
+        Returns a list of gradient dicts; `self.parameters` is left untouched."""
+        kwargs.pop('tqdm', None)
+        T_total = self._get_T(**kwargs)
+        grad_kwargs = {k: v for k, v in kwargs.items() if k != 'T'}
+        keep = self.parameters
+        groups_per_param = []
+        try:
+            for p in parameters_list:
+                self.parameters = p
+                groups_per_param.append(self._grad_groups(**grad_kwargs))
+        finally:
+            self.parameters = keep
+        flat = [q for groups in groups_per_param for group in groups for q, _ in group]
+        outs = iter(_pf.run_windows(flat))
+        names = self.message_helper.score_names
+        result = []
+        for p, groups in zip(parameters_list, groups_per_param):
+            grad = None
+            for group in groups:
+                part = {var: np.zeros_like(value) for var, value in p.as_dict().items()}
+                for _, minibatch_size in group:
+                    o = next(outs)
+                    for name, g in zip(names, o["mean_statistic"]):
+                        part[name] += g * 1.0 / minibatch_size
+                grad = part if grad is None else {var: grad[var] + part[var] for var in part}
+            grad = self._rescale_groups(grad, groups, **grad_kwargs)
+            prior = self.prior.grad_logprior(parameters=p)
+            total = {var: prior[var] + grad[var] for var in prior}
+            if is_scaled:
+                total = {var: total[var] / T_total for var in total}
+            for var in total:
+                if np.any(np.isnan(total[var])):
+                    raise ValueError("NaNs in gradient of {0}".format(var))
+            result.append(total)
+        return result
+
+    def _grad_groups(self, **kwargs):
+        """Window problems of one gradient at self.parameters: list (per series) of groups."""
+        return [self._grad_problems(**kwargs)]
+
+    def _rescale_groups(self, grad, groups, **kwargs):
         return grad
 
     # -- steps ---------------------------------------------------------------------------------------
@@ -548,13 +599,24 @@ class SeqSGMCMCSampler(object):
             value *= self._get_T(**kwargs) / S
         return value
 
-    def _noisy_grad_loglikelihood(self, num_sequences=-1, **kwargs):
+    def _grad_groups(self, num_sequences=-1, **kwargs):
         observations = self.observations
         groups, S = [], 0.0
         for index in self._choose_sequences(observations, num_sequences):
             groups.append(SGMCMCSampler._grad_problems(self, observations=observations[index], **kwargs))
             S += observations[index].shape[0]
-        grad = self._run_grad_problems(groups)
+        return groups
+
+    def _rescale_groups(self, grad, groups, num_sequences=-1, **kwargs):
         if num_sequences != -1:
+            S = self._seq_lengths_of(groups)
             grad = {var: grad[var] * self._get_T(**kwargs) / S for var in grad}
         return grad
+
+    def _seq_lengths_of(self, groups):
+        return float(sum(group[0][0]["_series_length"] for group in groups))
+
+    def _noisy_grad_loglikelihood(self, num_sequences=-1, **kwargs):
+        groups = self._grad_groups(num_sequences=num_sequences, **kwargs)
+        grad = self._run_grad_problems(groups)
+        return self._rescale_groups(grad, groups, num_sequences=num_sequences, **kwargs)

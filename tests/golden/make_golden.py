@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -370,9 +370,35 @@ def make_sampler_fixtures():
     np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
 
 
+
+
+def make_ksd_fixtures():
+    """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
+    from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
+    out, meta = {}, []
+    rs = np.random.RandomState(31)
+    for i, (K, d, c, beta, block) in enumerate([(50, 3, 1.0, 0.5, 1000), (200, 1, 1.0, 0.5, 1000),
+                                                (120, 4, 2.0, 0.3, 1000), (257, 3, 1.0, 0.5, 100)]):
+        x = rs.normal(size=(K, d))
+        g = -x * rs.uniform(0.5, 2.0, size=(1, d)) + 0.3 * rs.normal(size=(K, d))
+        val = IMQ_KSD(x, g, c=c, beta=beta, max_block_size=block)
+        key = "ksd{0}".format(i)
+        out[key + "/x"], out[key + "/g"], out[key + "/value"] = x, g, np.float64(val)
+        meta.append(dict(key=key, K=K, d=d, c=c, beta=beta))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "ksd.npz"), **out)
+
+
 if __name__ == "__main__":
-    make_pf_fixtures()
-    make_host_fixtures()
-    make_sampler_fixtures()
-    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz"):
-        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+    only = os.environ.get("GOLDEN_ONLY", "")        # e.g. GOLDEN_ONLY=ksd regenerates one file
+    if only in ("", "pf"):
+        make_pf_fixtures()
+    if only in ("", "host"):
+        make_host_fixtures()
+    if only in ("", "sampler"):
+        make_sampler_fixtures()
+    if only in ("", "ksd"):
+        make_ksd_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz"):
+        if os.path.exists(os.path.join(HERE, f)):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
