@@ -223,6 +223,100 @@ def sufficient_statistic(model, x, x_next):
     return np.hstack([x_next, x_next ** 2, x * x_next])
 
 
+def prior_log_density(model, d, x_t, x_next):
+    """Kernel.prior_log_density: log q(x_next | x_t) row-wise -> (L,).
+    kernels.py:102-126 (latent Gaussian, n = 1), garch/kernels.py:20-37."""
+    L = np.shape(x_t)[0]
+    if model == "garch":
+        sigma2_next = d["alpha"] + d["beta"] * x_t[:, 0] ** 2 + d["gamma"] * x_t[:, 1]
+        ll = -0.5 * x_next[:, 0] ** 2 / sigma2_next - 0.5 * LOG_2PI - 0.5 * np.log(sigma2_next)
+        return np.reshape(ll, (L))
+    diff = x_next - d["A"] * x_t
+    ll = -0.5 * (diff ** 2) * d["Qinv"] + -0.5 * LOG_2PI + np.log(d["LQinv"])
+    return np.reshape(ll, (L))
+
+
+def prior_log_density_max(model, d):
+    """Kernel.get_prior_log_density_max: kernels.py:128-138, garch/kernels.py:39-47."""
+    if model == "garch":
+        return -0.5 * LOG_2PI - 0.5 * np.log(d["alpha"])
+    return -0.5 * 1 * LOG_2PI + np.sum(np.log(np.diag(d["LQinv"])))
+
+
+class NpDraws(object):
+    """Uniform draws in the REFERENCE's order from a legacy generator: np.random.choice(size=L)
+    and np.random.rand(L) each take L doubles, choice(size=1) takes one."""
+
+    def __init__(self, rng):
+        self.rng = rng
+
+    def index_uniforms(self, t, j, r, L):
+        return self.rng.random_sample(len(L))
+
+    def accept_uniforms(self, t, j, r, L):
+        return self.rng.random_sample(len(L))
+
+    def manual_uniform(self, t, j, i):
+        return self.rng.random_sample(1)[0]
+
+
+class PoolDraws(object):
+    """Uniform draws addressed by (timestep, j, round, particle): what the device kernel reads.
+    idx_u, acc_u: [T, Ntilde, R, N]; man_u: [T, Ntilde, N]."""
+
+    def __init__(self, idx_u, acc_u, man_u):
+        self.idx_u, self.acc_u, self.man_u = idx_u, acc_u, man_u
+
+    def index_uniforms(self, t, j, r, L):
+        return self.idx_u[t, j, r, L]
+
+    def accept_uniforms(self, t, j, r, L):
+        return self.acc_u[t, j, r, L]
+
+    def manual_uniform(self, t, j, i):
+        return self.man_u[t, j, i]
+
+
+def paris_backward_indices(model, d, x, logw, x_next, Ntilde, draws, t,
+                           max_accept_reject=None, manual_sample_threshold=None):
+    """accept_reject_based_backward_sampling (pf.py:260-341): J[N, Ntilde]."""
+    N = np.shape(x)[0]
+    weights = log_normalize(logw)
+    ll_max = prior_log_density_max(model, d)
+    if max_accept_reject is None:
+        max_accept_reject = int(100 * np.log10(N / 10))
+    if manual_sample_threshold is None:
+        manual_sample_threshold = int(10 * np.log10(N / 10))
+    J = np.zeros((N, Ntilde), dtype=int)
+    for j in range(Ntilde):
+        L = [ii for ii in range(N)]
+        converged = False
+        for r in range(max_accept_reject):
+            size_L = len(L)
+            if size_L == 0:
+                converged = True
+                break
+            if size_L <= manual_sample_threshold:
+                break
+            indices = multinomial_ancestors(weights, draws.index_uniforms(t, j, r, L))
+            uniforms = draws.accept_uniforms(t, j, r, L)
+            child_ll = prior_log_density(model, d, x[indices], x_next[L])
+            threshold = np.exp(child_ll - ll_max)
+            new_L = []
+            for k in range(size_L):
+                if uniforms[k] <= threshold[k]:
+                    J[L[k], j] = indices[k]
+                else:
+                    new_L.append(L[k])
+            L = new_L
+        if not converged:
+            for i in L:
+                child_ll = prior_log_density(model, d, x, np.outer(np.ones(N), x_next[i]))
+                u = np.array([draws.manual_uniform(t, j, i)])
+                J[i, j] = multinomial_ancestors(log_normalize(logw + child_ll), u)[0]
+    return J
+
+
 STAT_DIM = {
     ("svm", "score"): 3, ("lgssm", "score"): 4, ("garch", "score"): 4,
     ("svm", "suff"): 3, ("lgssm", "suff"): 3, ("garch", "suff"): 3,
@@ -250,7 +344,8 @@ def draw_streams(rng, N, T):
 # --------------------------------------------------------------------------
 def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
               lambduh=None, stat="score", t1=0, tL=None, weights=None,
-              prior_mean=0.0, prior_var=1.0, save_all=False):
+              prior_mean=0.0, prior_var=1.0, save_all=False,
+              Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None):
     """One buffered PF window.
 
     Args:
@@ -271,9 +366,13 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         lambduh = 1.0
     elif pf == "nemeth":
         lambduh = 0.95 if lambduh is None else lambduh
+    elif pf == "paris":
+        if paris_draws is None:
+            raise ValueError("pf='paris' needs paris_draws (NpDraws or PoolDraws)")
     elif pf != "filter":
         raise ValueError("Unrecognized pf = {0}".format(pf))
     is_filter = (pf == "filter")
+    is_paris = (pf == "paris")
     d = derived(model, theta)
     if model == "svm" and abs(d["A"]) > 1:
         raise ValueError("Current AR parameter is |A| = {0} > 1".format(abs(d["A"])))
@@ -292,7 +391,7 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         if inside and weights is not None:
             weight_t = float(weights[t - t1])
 
-        if not is_filter:
+        if not is_filter and not is_paris:
             # nemeth_smoother: S from the *previous* weights (pf.py:161)
             S = np.sum(stats.T * log_normalize(logw), axis=1)
         # pf(): resample every step, propose, weight (pf.py:26-38)
@@ -301,6 +400,27 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         x_next = kernel_rv(model, kernel, d, parents, y[t], z[t])
         new_logw = kernel_reweight(model, kernel, d, parents, x_next, y[t])
 
+        if is_paris:
+            # paris_smoother (pf.py:183-258): rewire Ntilde backward-sampled parents per child
+            J = paris_backward_indices(model, d, x, logw, x_next, Ntilde, paris_draws, t,
+                                       max_accept_reject, manual_sample_threshold)
+            flat = J.flatten()
+            rew_parents = x[flat]
+            xi_next = x_next[np.array([ii for ii in range(N) for _ in range(Ntilde)])]
+            if inside and stat == "score":
+                add = score_statistic(model, d, rew_parents, xi_next, y[t])
+            elif inside and stat == "suff":
+                add = sufficient_statistic(model, rew_parents, xi_next)
+            else:
+                add = np.zeros((N * Ntilde, h))
+            add = add * weight_t
+            stats = np.mean(np.reshape(stats[flat] + add, (N, Ntilde, -1)), axis=1)
+            x, logw = x_next, new_logw
+            if inside:
+                loglik += weight_t * np.log(np.mean(np.exp(logw)))
+            if save_all:
+                all_x.append(x); all_lw.append(logw); all_s.append(stats); all_ll.append(loglik)
+            continue
         if inside and stat == "score":
             add = score_statistic(model, d, parents, x_next, y[t])
         elif inside and stat == "suff":
@@ -339,10 +459,34 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
 
 def pf_window_rng(model, theta, y, N, rng=np.random, **kw):
     """pf_window drawing its streams from `rng` in the reference's order; the drop-in
-    equivalent of Helper.pf_gradient_estimate's inner buffered_pf_wrapper call."""
+    equivalent of Helper.pf_gradient_estimate's inner buffered_pf_wrapper call.
+    (Not for pf='paris': its draws interleave data-dependently with the filter's; use
+    pf_window_paris_rng.)"""
     T = np.asarray(y).reshape(-1).shape[0]
     z0, u, z = draw_streams(rng, N, T)
     return pf_window(model, theta, y, N, z0, u, z, **kw)
+
+
+class _LazyStreams(object):
+    """u[t] / z[t] drawn from the generator at first access, so that a PaRIS run consumes the
+    legacy stream in the reference's interleaved order: per timestep N uniforms, N normals
+    (pf()), then the backward-sampling draws."""
+
+    def __init__(self, rng, N, kind):
+        self.rng, self.N, self.kind, self.cache = rng, N, kind, {}
+
+    def __getitem__(self, t):
+        if t not in self.cache:
+            self.cache[t] = (self.rng.random_sample(self.N) if self.kind == "u"
+                             else self.rng.normal(size=self.N))
+        return self.cache[t]
+
+
+def pf_window_paris_rng(model, theta, y, N, rng=np.random, **kw):
+    """PaRIS window consuming `rng` exactly as the reference does."""
+    z0 = rng.normal(size=N)
+    return pf_window(model, theta, y, N, z0, _LazyStreams(rng, N, "u"), _LazyStreams(rng, N, "z"),
+                     pf="paris", paris_draws=NpDraws(rng), **kw)
 
 
 def pf_gradient_estimate(model, theta, y, N, rng=np.random, **kw):

@@ -40,13 +40,35 @@ def _smoother_of(pf, kwargs):
     raise ValueError("Unrecognized pf = {0}".format(pf))
 
 
-def draw_replay_streams(N, T, random_state=None):
+# Stream buffers are recycled between calls: a fresh 16 MB ndarray costs ~45 ms of first-touch
+# page faults, more than generating its contents (T = N = 1000).
+_stream_pool = {}
+_STREAM_POOL_MAX_BYTES = 512 << 20
+
+
+def _stream_buffers(N, T):
+    free = _stream_pool.get((N, T))
+    if free:
+        return free.pop()
+    return np.empty((T, N)), np.empty((T, N))
+
+
+def _recycle_streams(problems):
+    """Return the u/z buffers of finished problems to the pool (the C call has copied them)."""
+    held = sum(len(v) * 2 * k[0] * k[1] * 8 for k, v in _stream_pool.items())
+    for q in problems:
+        bufs = q.pop("_stream_bufs", None)
+        if bufs is not None and held < _STREAM_POOL_MAX_BYTES:
+            _stream_pool.setdefault(bufs[0].shape[::-1], []).append(bufs)
+            held += 2 * bufs[0].nbytes
+
+
+def draw_replay_streams(N, T, random_state=None, buffers=None):
     """Take from `random_state` (default: the global legacy np.random) exactly what one
     reference PF run takes, in its order.  Returns z0 (N,), u (T,N), z (T,N)."""
     rs = np.random if random_state is None else random_state
     z0 = rs.normal(size=N)
-    u = np.empty((T, N))
-    z = np.empty((T, N))
+    u, z = buffers if buffers is not None else (np.empty((T, N)), np.empty((T, N)))
     for t in range(T):
         u[t] = rs.random_sample(N)
         z[t] = rs.normal(size=N)
@@ -76,7 +98,9 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
              prior_var=float(np.asarray(prior_var).reshape(-1)[0]),
              y=y, weights=weights, theta=theta, flags=flags)
     if rng == "replay":
-        q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state)
+        bufs = _stream_buffers(int(N), T)
+        q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state, buffers=bufs)
+        q["_stream_bufs"] = bufs
     elif rng in ("device", "philox"):
         if seed is None:
             # derive the device key from the host stream so np.random.seed() still controls runs
@@ -101,7 +125,9 @@ def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
     q = make_problem(model, kernel, pf, observations, theta, N, **kwargs)
     ctx = ctx or _capi.default_context()
     o = ctx.run_batch([q], want_final=want_final or save_all, want_trace=save_all)[0]
-    return _to_reference_dict(o, q)
+    out = _to_reference_dict(o, q)
+    _recycle_streams([q])
+    return out
 
 
 def _to_reference_dict(o, q):
@@ -124,7 +150,9 @@ def run_windows(problems, ctx=None, want_final=False):
     """Many independent windows (same model/kernel/dtype/rng) in ONE launch, one workgroup each."""
     ctx = ctx or _capi.default_context()
     outs = ctx.run_batch(problems, want_final=want_final)
-    return [_to_reference_dict(o, q) for o, q in zip(outs, problems)]
+    res = [_to_reference_dict(o, q) for o, q in zip(outs, problems)]
+    _recycle_streams(problems)
+    return res
 
 
 def average_statistic(out):

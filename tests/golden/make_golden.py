@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -372,6 +372,43 @@ def make_sampler_fixtures():
 
 
 
+def make_paris_fixtures():
+    """PaRIS smoother (pf.py:183-341) traces: default settings and settings that force the
+    manual-sampling fallback."""
+    out, meta = {}, []
+    combos = [("svm", "prior"), ("garch", "optimal"), ("garch", "prior"), ("lgssm", "optimal"), ("lgssm", "prior")]
+    N, T, t1, tL = 32, 12, 2, 10
+    for ci, (model, kernel) in enumerate(combos):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(500 + ci)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        pm, pv = prior_x(model, p, data)
+        weights = 1.0 + 0.5 * np.arange(tL - t1)
+        for vi, kw in enumerate([dict(), dict(Ntilde=3, max_accept_reject=3, manual_sample_threshold=0),
+                                 dict(Ntilde=1, max_accept_reject=40, manual_sample_threshold=0)]):
+            seed = 7000 + 10 * ci + vi
+            K = cfg["kernels"][kernel]()
+            np.random.seed(seed)
+            o = buffered_pf_wrapper(pf="paris", observations=y, parameters=p, N=N, kernel=K,
+                                    additive_statistic_func=cfg["score"], statistic_dim=cfg["h"],
+                                    t1=t1, tL=tL, weights=weights, prior_mean=np.array([pm]),
+                                    prior_var=np.array([[pv]]) if model != "garch" else pv,
+                                    save_all=True, **kw)
+            key = "p{0}".format(len(meta))
+            meta.append(dict(key=key, model=model, kernel=kernel, N=N, T=T, t1=t1, tL=tL, seed=seed,
+                             prior_mean=pm, prior_var=pv, kwargs=kw))
+            out[key + "/y"] = y.reshape(-1)
+            out[key + "/theta"] = theta_of(model, p)
+            out[key + "/weights"] = weights
+            for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+                out[key + "/" + name] = np.asarray(o[name], dtype=float)
+            out[key + "/mean_statistic"] = average_statistic(o)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "paris.npz"), **out)
+
+
 def make_ksd_fixtures():
     """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
     from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
@@ -399,6 +436,8 @@ if __name__ == "__main__":
         make_sampler_fixtures()
     if only in ("", "ksd"):
         make_ksd_fixtures()
-    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz"):
+    if only in ("", "paris"):
+        make_paris_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

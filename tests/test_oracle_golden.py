@@ -94,3 +94,21 @@ def test_multinomial_matches_numpy_choice():
     assert np.array_equal(idx, po.multinomial_ancestors(p, u))
     # both consumed exactly 50 doubles
     assert s1.random_sample() == s2.random_sample()
+
+
+def test_paris_oracle_bit_exact():
+    """PaRIS smoother restatement vs the reference's traces (default settings and forced
+    manual-sampling fallback), consuming the legacy stream in the reference's order."""
+    from conftest import Golden
+    g = Golden("paris.npz")
+    assert len(g.meta) == 15
+    for meta in g.meta:
+        key = meta["key"]
+        rng = np.random.RandomState(meta["seed"])
+        out = po.pf_window_paris_rng(meta["model"], g.get(key, "theta"), g.get(key, "y"), meta["N"], rng=rng,
+                                     kernel=meta["kernel"], stat="score", t1=meta["t1"], tL=meta["tL"],
+                                     weights=g.get(key, "weights"), prior_mean=meta["prior_mean"],
+                                     prior_var=meta["prior_var"], save_all=True, **meta["kwargs"])
+        for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+            assert np.array_equal(np.asarray(out[name], dtype=float), g.get(key, name)), (meta, name)
+        assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic"))
