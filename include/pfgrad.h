@@ -47,8 +47,10 @@ typedef struct pfg_ctx pfg_ctx;
 enum pfg_model { PFG_MODEL_SVM = 0, PFG_MODEL_GARCH = 1, PFG_MODEL_LGSSM = 2 };
 /* proposal kernels: models/{svm,garch,lgssm}/kernels.py ("prior" bootstrap, "optimal") */
 enum pfg_kernel { PFG_KERNEL_PRIOR = 0, PFG_KERNEL_OPTIMAL = 1 };
-/* smoothers: particle_filters/pf.py:138-181 (nemeth; poyiadjis_N = lambduh 1.0), :40-82 (filter) */
-enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1 };
+/* smoothers: particle_filters/pf.py:138-181 (nemeth; poyiadjis_N = lambduh 1.0), :40-82 (filter),
+ * :183-341 (PaRIS: Ntilde backward-sampled parents per child by accept-reject, exact
+ * categorical fallback after max_accept_reject rounds; N <= 1024) */
+enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTHER_PARIS = 2 };
 /* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
 enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2 };
 /* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
@@ -86,6 +88,11 @@ typedef struct pfg_problem {
     const double *z0, *u, *z;/* REPLAY streams: [N], [T*N], [T*N]; NULL for DEVICE */
     uint64_t seed, stream;   /* DEVICE rng: key and stream id (global chain id) */
     const double *init_x, *init_logw, *init_stats; /* optional warm start: [N*n],[N],[N*h] */
+    /* PaRIS only.  REPLAY pools of uniforms addressed by (timestep, j, round, particle):
+     * paris_idx_u / paris_acc_u [T][Ntilde][max_accept_reject][N] (index draw, accept draw),
+     * paris_man_u [T][Ntilde][N] (fallback draw); NULL with the DEVICE rng. */
+    int32_t Ntilde, max_accept_reject;
+    const double *paris_idx_u, *paris_acc_u, *paris_man_u;
 } pfg_problem;
 
 /* Result of one window; optional arrays are caller-allocated HOST buffers or NULL. */
@@ -124,6 +131,8 @@ typedef struct pfg_dev_problem {
     int32_t smoother, stat;
     uint32_t flags;
     int32_t reserved;
+    const double *paris_idx_u, *paris_acc_u, *paris_man_u;   /* PaRIS REPLAY pools (see pfg_problem) */
+    int32_t Ntilde, max_accept_reject;
 } pfg_dev_problem;
 
 int pfg_version(void);
@@ -149,6 +158,11 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
  * n_max = the largest N in the batch (selects the kernel variant). */
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+/* as pfg_launch_device for a batch whose descriptors all have smoother = `smoother`
+ * (PFG_SMOOTHER_PARIS needs its own kernel variant and LDS budget; the plain entry point
+ * serves NEMETH / FILTER) */
+int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
+                               int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 /* bytes of per-problem HBM scratch (pfg_dev_problem.scratch, 256-byte aligned) the large-N
  * kernel needs for (model, dtype, rng, N); 0 when an LDS-resident variant serves this size,
  * -1 when N is above the supported maximum (16384) */

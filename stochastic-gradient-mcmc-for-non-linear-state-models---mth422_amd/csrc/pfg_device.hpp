@@ -279,6 +279,7 @@ template <typename REAL> struct Consts {
     REAL opt_sd, opt_prec, opt_var, opt_logvar;         // lgssm optimal kernel
     // garch
     REAL mu, phi, lam, alpha, beta, gamma;
+    REAL logalpha, logLQinv;                            // PaRIS backward kernel
 };
 
 template <int MODEL, typename REAL>
@@ -307,6 +308,9 @@ __device__ __forceinline__ Consts<REAL> make_consts(const double *__restrict__ t
     if (MODEL != PFG_MODEL_GARCH) {
         d.iLQinv = 1.0 / d.LQinv;
         d.Qinv = d.LQinv * d.LQinv + 1e-16;
+        d.logLQinv = log(d.LQinv);
+    } else {
+        d.logalpha = log(d.alpha);
     }
     if (MODEL == PFG_MODEL_LGSSM) {
         d.opt_prec = d.Qinv + (d.C * d.C) * d.Rinv;
@@ -323,6 +327,7 @@ __device__ __forceinline__ Consts<REAL> make_consts(const double *__restrict__ t
     c.opt_logvar = (REAL)d.opt_logvar;
     c.mu = (REAL)d.mu; c.phi = (REAL)d.phi; c.lam = (REAL)d.lam;
     c.alpha = (REAL)d.alpha; c.beta = (REAL)d.beta; c.gamma = (REAL)d.gamma;
+    c.logalpha = (REAL)d.logalpha; c.logLQinv = (REAL)d.logLQinv;
     return c;
 }
 
@@ -423,6 +428,61 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
 // (larger N fits in 160 KiB) at the price of a 4th barrier and of holding all gathered
 // parents in registers across it.
 // ------------------------------------------------------------------------------------
+// Additive statistic h(parent, child) alone (PaRIS evaluates it for rewired parents): the same
+// expressions as in particle_step.  `aux` carries the child's sub-expression the proposal step
+// already has (SVM: exp(-x')).
+template <int MODEL, int STAT, typename REAL>
+__device__ __forceinline__ void additive_stat(const Consts<REAL> &c, const REAL *xp, const REAL *xn, REAL y,
+                                              REAL aux, REAL *add) {
+    constexpr int H = ModelDims<MODEL>::H;
+    const REAL half = (REAL)0.5;
+#pragma unroll
+    for (int h = 0; h < H; ++h) add[h] = (REAL)0;
+    if (STAT != PFG_STAT_SCORE) {
+        if (MODEL == PFG_MODEL_GARCH) { REAL x2 = xn[0] * xn[0]; add[0] = xn[0]; add[1] = x2; add[2] = x2 * x2; }
+        else { add[0] = xn[0]; add[1] = xn[0] * xn[0]; add[2] = xp[0] * xn[0]; }
+        return;
+    }
+    if (MODEL == PFG_MODEL_SVM) {
+        REAL dx = xn[0] - c.A * xp[0];
+        add[2] = (c.Qinv * dx) * xp[0];
+        add[1] = c.iLQinv - (dx * dx) * c.LQinv;
+        add[0] = c.iLRinv - ((y * y) * aux) * c.LRinv;
+    } else if (MODEL == PFG_MODEL_LGSSM) {
+        REAL dx = xn[0] - c.A * xp[0];
+        add[3] = (c.Qinv * dx) * xp[0];
+        add[1] = c.iLQinv - (dx * dx) * c.LQinv;
+        REAL dy = y - c.C * xn[0];
+        add[2] = (c.Rinv * dy) * xn[0];
+        add[0] = c.iLRinv - (dy * dy) * c.LRinv;
+    } else {
+        REAL xx = xp[0] * xp[0];
+        REAL v = xn[1];
+        REAL gv = (-half * (v - xn[0] * xn[0])) / (v * v);
+        add[1] = (gv * ((REAL)1 - c.phi)) * c.mu;
+        add[2] = ((gv * ((-c.mu + c.lam * xx) + ((REAL)1 - c.lam) * xp[1])) * ((REAL)1 - c.phi)) * c.phi;
+        add[3] = (((gv * c.phi) * (xx - xp[1])) * ((REAL)1 - c.lam)) * c.lam;
+        REAL dy = y - xn[0];
+        add[0] = c.iLRinv - (dy * dy) * c.LRinv;
+    }
+}
+
+// log q(child | parent) - max q: the accept-reject exponent of PaRIS backward sampling
+// (Kernel.prior_log_density - get_prior_log_density_max; kernels.py:102-138, garch/kernels.py:20-47)
+template <int MODEL, typename REAL, typename MATH>
+__device__ __forceinline__ REAL backward_log_ratio(const Consts<REAL> &c, const MATH &mth, const REAL *xp,
+                                                   const REAL *xn) {
+    const REAL half = (REAL)0.5;
+    if (MODEL == PFG_MODEL_GARCH) {
+        REAL s2 = (c.alpha + c.beta * (xp[0] * xp[0])) + c.gamma * xp[1];
+        REAL ll = ((-half * (xn[0] * xn[0])) / s2 - half * (REAL)LOG_2PI) - half * mth.log(s2);
+        return ll - (-half * (REAL)LOG_2PI - half * c.logalpha);
+    }
+    REAL diff = xn[0] - c.A * xp[0];
+    REAL ll = ((-half * (diff * diff)) * c.Qinv + -half * (REAL)LOG_2PI) + c.logLQinv;
+    return ll - (-half * (REAL)LOG_2PI + c.logLQinv);
+}
+
 __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
 // FAST layout = LDS math tables + sentinel-padded, bank-conflict-free cdf with an unrolled search.
 // Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
@@ -435,13 +495,14 @@ template <int NT, int PPT> struct RegLayout {
 
 // PP variants: cdf has NT*PPT entries (tail = sentinel 2.0 -> unrolled, clamp-free search) and
 // the fp64 math runs on LDS tables; the single-buffer variant spends its LDS on particles.
-template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP>
+template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool PARIS = false>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
     constexpr bool FAST = fast_layout(NT, PP);
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
-           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>();
+           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
+           (PARIS ? (NL * sizeof(REAL) + 7) / 8 * 8 : 0);     // PaRIS keeps the parents' log-weights in LDS
 }
 
 // waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
@@ -454,8 +515,9 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP)
     return (NT == 256 && PPT == 4 && !PP) ? 3 : 1;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool PARIS = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+    static_assert(!PARIS || PP, "PaRIS needs the parents intact while children are built: ping-pong buffers");
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NW = NT / WAVE;
@@ -468,7 +530,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
     const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : P.lambduh;
+    const double lam_d = is_filter ? 0.0 : (P.smoother == PFG_SMOOTHER_PARIS ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const double *__restrict__ const yv = P.y;
@@ -492,6 +554,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;           // [H*NW]
     double *tabmem = red + RegLayout<NT, PPT>::RED;
+    REAL *lwL = reinterpret_cast<REAL *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8);    // [NL], PARIS only
 
     Math<REAL, TAB> mth;
     mth.t.e2 = tabmem;
@@ -696,7 +759,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         const bool plain = !needS_every;                 // not filter and lambda == 1
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (valid[k]) cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
+            if (valid[k]) {
+                cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
+                if (PARIS) lwL[k * NT + tid] = lw[k];
+            }
         __syncthreads();                                                        // barrier 3
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
@@ -784,8 +850,117 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 }
             }
         };
-        if (stat == PFG_STAT_SCORE) slots(std::integral_constant<int, PFG_STAT_SCORE>{});
-        else slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+        // PaRIS (pf.py:183-341): children are proposed from the filter's ancestors as above, then
+        // every child draws Ntilde parents from the backward kernel  w_k q(child | x_k)  by
+        // accept-reject against the filter weights (exact categorical fallback after
+        // max_accept_reject rounds) and averages  stats[J] + w_t h(x_J, child)  over them.
+        auto paris_slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            const int Nt = P.Ntilde, R = P.max_accept_reject;
+            const double *__restrict__ const pidx = P.paris_idx_u;
+            const double *__restrict__ const pacc = P.paris_acc_u;
+            const double *__restrict__ const pman = P.paris_man_u;
+            auto search_cdf = [&](double u) {
+                int pos = 0;
+#pragma unroll
+                for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                    pos += (cdf[pos + probe] <= u) ? step + (step >> 5) : 0;
+                }
+                pos -= (pos * 993) >> 15;
+                return pos < last ? pos : last;
+            };
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = k * NT + tid;
+                REAL xp[NS], xn[NS], add[H], lwn;
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn, lwn, add);
+                const REAL aux = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[0]) : (REAL)0;
+                REAL sacc[H];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sacc[h] = (REAL)0;
+                for (int j = 0; j < Nt; ++j) {
+                    int J = -1;
+                    for (int r = 0; r < R; ++r) {
+                        const bool pend = valid[k] && J < 0;
+                        if (!__any(pend)) break;
+                        double u1, u2;
+                        if (RNG == PFG_RNG_REPLAY) {
+                            const size_t at = (((size_t)t * Nt + j) * R + r) * N + own[k];
+                            u1 = pidx[at]; u2 = pacc[at];
+                        } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
+                        const int I = search_cdf(u1);
+                        REAL xI[NS];
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NL + I];
+                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn));
+                        if (pend && u2 <= thr) J = I;
+                    }
+                    if (valid[k] && J < 0) {
+                        // exact draw from softmax_k(logw_k + log q(child | x_k)): max, total, search
+                        const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
+                                                                  : u01_32(rng.next());
+                        REAL mx = -INFINITY;
+                        for (int q = 0; q < N; ++q) {
+                            REAL xq[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
+                            const REAL l = lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn);
+                            mx = l > mx ? l : mx;
+                        }
+                        double tot = 0.0;
+                        for (int q = 0; q < N; ++q) {
+                            REAL xq[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
+                            tot += (double)mth.exp((lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn)) - mx);
+                        }
+                        const double target = um * tot;
+                        double run = 0.0;
+                        J = last;
+                        for (int q = 0; q < N; ++q) {
+                            REAL xq[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
+                            run += (double)mth.exp((lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn)) - mx);
+                            if (run > target) { J = q; break; }
+                        }
+                    }
+                    J = J < 0 ? 0 : J;
+                    REAL xJ[NS], aj[H];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + J];
+                    additive_stat<MODEL, STAT, REAL>(c, xJ, xn, (REAL)y_t, aux, aj);
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                        sacc[h] += cur[(size_t)(NS + h) * NL + J] + a;
+                    }
+                }
+                lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
+                if (valid[k]) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sacc[h] / (REAL)Nt;
+                }
+            }
+        };
+        bool did_paris = false;
+        if constexpr (PARIS) {
+            if (P.smoother == PFG_SMOOTHER_PARIS) {
+                if (stat == PFG_STAT_SCORE) paris_slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+                else paris_slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+                did_paris = true;
+            }
+        }
+        if (!did_paris) {
+            if (stat == PFG_STAT_SCORE) slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+        }
         if (P.trace_x) {
             // own children back from LDS (written by this thread: no barrier needed)
 #pragma unroll

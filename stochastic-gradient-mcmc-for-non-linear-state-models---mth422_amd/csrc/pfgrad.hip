@@ -131,6 +131,30 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
 }
 
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+int launch_paris_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, true>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, true>(n_max);
+    if (lds > kLdsLimit)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 256) return launch_paris_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
+    if (n_max <= 1024) return launch_paris_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
+}
+
+constexpr int kVariantParis = -3;
+
 template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
@@ -148,6 +172,14 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 template <int MODEL, int KERNEL>
 int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
               hipStream_t st) {
+    if (v == kVariantParis) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_paris<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_paris<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+    }
     if (v == kVariantMem) {
         if (dtype == PFG_F64) {
             if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
@@ -176,12 +208,12 @@ int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
 }
 
 int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
-             const pfg_dev_problem *dp, hipStream_t st) {
+             const pfg_dev_problem *dp, hipStream_t st, int smoother = PFG_SMOOTHER_NEMETH) {
     int rc = check_combo(ctx, model, kernel, dtype, rng);
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
-    int v = pick_variant(model, dtype, rng, n_max);
+    int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis : pick_variant(model, dtype, rng, n_max);
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
@@ -366,6 +398,16 @@ int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, i
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream);
 }
 
+int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother, int n_max,
+                               int B, const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_smoother: dev_probs is NULL");
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_PARIS)
+        return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother);
+}
+
 int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
                            const pfg_prior_hyper *hyper, double epsilon, double Tscale, uint64_t seed,
                            uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream) {
@@ -431,8 +473,16 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (q.N < 1) return fail(ctx, PFG_ERR_INVALID, id + "N must be >= 1");
         if (q.T < 0) return fail(ctx, PFG_ERR_INVALID, id + "T must be >= 0");
         if (q.t1 < 0 || q.tL < q.t1) return fail(ctx, PFG_ERR_INVALID, id + "need 0 <= t1 <= tL");
-        if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_FILTER)
+        if (q.smoother < PFG_SMOOTHER_NEMETH || q.smoother > PFG_SMOOTHER_PARIS)
             return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
+        if ((q.smoother == PFG_SMOOTHER_PARIS) != (ps[0].smoother == PFG_SMOOTHER_PARIS))
+            return fail(ctx, PFG_ERR_INVALID, id + "pf = 'paris' cannot share a batch with other smoothers");
+        if (q.smoother == PFG_SMOOTHER_PARIS) {
+            if (q.Ntilde < 1 || q.Ntilde > 64) return fail(ctx, PFG_ERR_INVALID, id + "Ntilde must be in [1, 64]");
+            if (q.max_accept_reject < 0) return fail(ctx, PFG_ERR_INVALID, id + "max_accept_reject must be >= 0");
+            if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u))))
+                return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools");
+        }
         if (q.stat < PFG_STAT_SCORE || q.stat > PFG_STAT_NONE) return fail(ctx, PFG_ERR_INVALID, id + "bad stat id");
         if (!q.theta) return fail(ctx, PFG_ERR_INVALID, id + "theta is NULL");
         if (q.T > 0 && !q.y) return fail(ctx, PFG_ERR_INVALID, id + "observations are NULL");
@@ -452,6 +502,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         n_in += (size_t)q.T + (nw > 0 ? nw : 0) + PFG_MAX_THETA;
         if (rng == PFG_RNG_REPLAY) n_in += (q.z0 ? (size_t)q.N : 0) + 2 * (size_t)q.T * q.N;
         if (q.init_x) n_in += (size_t)q.N * (NS + 1) + (q.init_stats ? (size_t)q.N * H : 0);
+        if (q.smoother == PFG_SMOOTHER_PARIS && rng == PFG_RNG_REPLAY)
+            n_in += (size_t)q.T * q.Ntilde * q.N * (1 + 2 * (size_t)q.max_accept_reject);
         const pfg_result &r = rs[b];
         n_out += PFG_OUT_DOUBLES;
         if (r.x_T) n_out += (size_t)q.N * NS;
@@ -466,7 +518,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
-    const int variant = pick_variant(model, dtype, rng, n_max);
+    const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
+    const int variant = paris ? kVariantParis : pick_variant(model, dtype, rng, n_max);
     if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
@@ -528,6 +581,15 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             d.init_logw = put(q.init_logw, q.N);
             d.init_stats = put(q.init_stats, q.init_stats ? (size_t)q.N * H : 0);
         }
+        if (paris) {
+            d.Ntilde = q.Ntilde; d.max_accept_reject = q.max_accept_reject;
+            if (rng == PFG_RNG_REPLAY) {
+                const size_t pool = (size_t)q.T * q.Ntilde * q.max_accept_reject * q.N;
+                d.paris_idx_u = put(q.paris_idx_u, pool);
+                d.paris_acc_u = put(q.paris_acc_u, pool);
+                d.paris_man_u = put(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
+            }
+        }
         d.out = take(true, PFG_OUT_DOUBLES);
         d.final_x = take(r.x_T != nullptr, (size_t)q.N * NS);
         d.final_logw = take(r.logw_T != nullptr, q.N);
@@ -551,7 +613,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
     rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
-                  ctx->stream);
+                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : PFG_SMOOTHER_NEMETH);
     if (rc) return rc;
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));

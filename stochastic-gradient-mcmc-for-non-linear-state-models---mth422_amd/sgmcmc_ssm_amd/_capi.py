@@ -12,7 +12,7 @@ from . import _build
 # ---- enums (include/pfgrad.h) ---------------------------------------------------------
 MODEL = {"svm": 0, "garch": 1, "lgssm": 2}
 KERNEL = {"prior": 0, "optimal": 1}
-SMOOTHER = {"nemeth": 0, "filter": 1}
+SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2}
 STAT = {"score": 0, "suff": 1, "none": 2}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
@@ -38,6 +38,8 @@ class Problem(C.Structure):
         ("z0", _dp), ("u", _dp), ("z", _dp),
         ("seed", C.c_uint64), ("stream", C.c_uint64),
         ("init_x", _dp), ("init_logw", _dp), ("init_stats", _dp),
+        ("Ntilde", C.c_int32), ("max_accept_reject", C.c_int32),
+        ("paris_idx_u", _dp), ("paris_acc_u", _dp), ("paris_man_u", _dp),
     ]
 
 
@@ -71,10 +73,12 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("seed", "u8"), ("stream", "u8"),
     ("T", "i4"), ("t1", "i4"), ("tL", "i4"), ("N", "i4"),
     ("smoother", "i4"), ("stat", "i4"), ("flags", "u4"), ("reserved", "i4"),
+    ("paris_idx_u", "u8"), ("paris_acc_u", "u8"), ("paris_man_u", "u8"),
+    ("Ntilde", "i4"), ("max_accept_reject", "i4"),
 ], align=True)
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
-           "pfg_ctx_stream", "pfg_launch_device", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
+           "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_imq_ksd")
 
 _lib = None
@@ -134,6 +138,8 @@ def load_library():
     lib.pfg_launch_device.restype = C.c_int
     lib.pfg_ctx_stream.argtypes = [C.c_void_p]
     lib.pfg_ctx_stream.restype = C.c_void_p
+    lib.pfg_launch_device_smoother.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    lib.pfg_launch_device_smoother.restype = C.c_int
     lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
@@ -226,7 +232,10 @@ class Context:
             p.prior_var = float(q.get("prior_var", 1.0))
             theta = _as_f64(q["theta"]).reshape(-1)
             arrs = dict(y=y, theta=theta)
-            for name in ("weights", "z0", "u", "z", "init_x", "init_logw", "init_stats"):
+            p.Ntilde = int(q.get("Ntilde", 2))
+            p.max_accept_reject = int(q.get("max_accept_reject", 0))
+            for name in ("weights", "z0", "u", "z", "init_x", "init_logw", "init_stats",
+                         "paris_idx_u", "paris_acc_u", "paris_man_u"):
                 v = q.get(name, None)
                 arrs[name] = None if v is None else _as_f64(v).reshape(-1)
             if arrs["weights"] is not None and arrs["weights"].shape[0] < p.tL - p.t1:
@@ -243,6 +252,11 @@ class Context:
             keep.append(arrs)
             o = {}
             r = rs[b]
+            if p.smoother == SMOOTHER["paris"] and p.rng == RNG["replay"]:
+                pool = T * p.Ntilde * p.max_accept_reject * N
+                for name, need in (("paris_idx_u", pool), ("paris_acc_u", pool), ("paris_man_u", T * p.Ntilde * N)):
+                    if need and (arrs[name] is None or arrs[name].shape[0] != need):
+                        raise ValueError("{0} must have {1} entries".format(name, need))
             is_filter = p.smoother == SMOOTHER["filter"]
             if want_final or want_trace:
                 o["x_t"] = np.zeros((N, ns))

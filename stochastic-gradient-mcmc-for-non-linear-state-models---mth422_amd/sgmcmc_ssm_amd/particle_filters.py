@@ -20,8 +20,8 @@ import numpy as np
 
 from . import _capi
 
-PF_NAMES = ("nemeth", "poyiadjis_N", "filter")
-NOT_ON_DEVICE = ("poyiadjis_N2", "paris")      # SURVEY.md 8(f) "next" rows
+PF_NAMES = ("nemeth", "poyiadjis_N", "filter", "paris")
+NOT_ON_DEVICE = ("poyiadjis_N2",)              # SURVEY.md 8(f) "next" row
 
 
 def _smoother_of(pf, kwargs):
@@ -34,9 +34,12 @@ def _smoother_of(pf, kwargs):
     if pf == "filter":
         kwargs.pop("lambduh", None)
         return "filter", 1.0
+    if pf == "paris":
+        kwargs.pop("lambduh", None)
+        return "paris", 1.0
     if pf in NOT_ON_DEVICE:
         raise NotImplementedError(
-            "pf = '{0}' is not implemented on the HIP backend yet (O(N^2) / PaRIS smoothers)".format(pf))
+            "pf = '{0}' is not implemented on the HIP backend yet (O(N^2) smoother)".format(pf))
     raise ValueError("Unrecognized pf = {0}".format(pf))
 
 
@@ -92,8 +95,29 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
             raise ValueError("the HIP particle filter supports m = 1 observations only")
         y = y[:, 0]
     T = y.shape[0]
+    paris_kw = {}
+    if smoother == "paris":
+        # PaRIS (pf.py:183-341).  Its backward-sampling draws are data-dependent in number, so the
+        # reference's np.random order cannot be replayed from pre-drawn streams: unless explicit
+        # uniform pools are passed (tests), the device generator is used, keyed from np.random
+        # (reproducible under np.random.seed; statistically equivalent to the reference).
+        # `manual_sample_threshold` (an early exit to the exact fallback) is a host-speed knob of
+        # the reference and is not needed here: every child runs accept-reject for
+        # max_accept_reject rounds, then the same exact categorical fallback.
+        if not kwargs.pop("accept_reject", True):
+            raise NotImplementedError("PaRIS with accept_reject=False (O(N^2)) is not on the HIP backend")
+        kwargs.pop("manual_sample_threshold", None)
+        mar = kwargs.pop("max_accept_reject", None)
+        paris_kw["Ntilde"] = int(kwargs.pop("Ntilde", 2))
+        paris_kw["max_accept_reject"] = int(100 * np.log10(int(N) / 10)) if mar is None else int(mar)
+        paris_kw["max_accept_reject"] = max(0, paris_kw["max_accept_reject"])
+        pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
+        if rng == "replay" and pools[2] is None:
+            rng = "device"
+        elif rng == "replay":
+            paris_kw.update(paris_idx_u=pools[0], paris_acc_u=pools[1], paris_man_u=pools[2])
     q = dict(model=model, kernel=kernel, smoother=smoother, stat=stat, dtype=dtype, rng=rng,
-             N=int(N), t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=lambduh,
+             N=int(N), t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=lambduh, **paris_kw,
              prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
              prior_var=float(np.asarray(prior_var).reshape(-1)[0]),
              y=y, weights=weights, theta=theta, flags=flags)

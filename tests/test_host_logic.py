@@ -233,7 +233,7 @@ def test_unsupported_paths_raise():
     with pytest.raises(NotImplementedError):
         s.noisy_gradient(kind="marginal")
     with pytest.raises(NotImplementedError):
-        s.noisy_gradient(kind="pf", pf="paris", N=10)
+        s.noisy_gradient(kind="pf", pf="poyiadjis_N2", N=10)
     with pytest.raises(ValueError):
         s.noisy_gradient(kind="pf", pf="bogus", N=10)
     with pytest.raises(NotImplementedError):
