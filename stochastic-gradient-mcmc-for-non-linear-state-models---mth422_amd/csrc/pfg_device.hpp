@@ -502,7 +502,7 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
-           (PARIS ? (NL * sizeof(REAL) + 7) / 8 * 8 : 0);     // PaRIS keeps the parents' log-weights in LDS
+           (PARIS ? NL * 8 + NL * 4 : 0);     // PaRIS: parents' log-weights + fallback queue in LDS
 }
 
 // waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     double *red_S = red_max + NW;           // [H*NW]
     double *tabmem = red + RegLayout<NT, PPT>::RED;
     REAL *lwL = reinterpret_cast<REAL *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8);    // [NL], PARIS only
+    int *paris_queue = reinterpret_cast<int *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8 + NL);   // [NL], PARIS only
 
     Math<REAL, TAB> mth;
     mth.t.e2 = tabmem;
@@ -860,92 +861,159 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
             const double *__restrict__ const pidx = P.paris_idx_u;
             const double *__restrict__ const pacc = P.paris_acc_u;
             const double *__restrict__ const pman = P.paris_man_u;
-            auto search_cdf = [&](double u) {
-                int pos = 0;
-#pragma unroll
-                for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
-                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
-                    pos += (cdf[pos + probe] <= u) ? step + (step >> 5) : 0;
-                }
-                pos -= (pos * 993) >> 15;
-                return pos < last ? pos : last;
-            };
+            int *queue = paris_queue;                               // [<= N] children left to the fallback
+            int *qcount = reinterpret_cast<int *>(red_max) + NW;    // behind the NW floats of red_maxf
+            // ---- 1. propose every child from its filter ancestor and publish x' -------------
             if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+            REAL xn[PPT][NS], lwn[PPT], aux[PPT], sacc[PPT][H];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int i = k * NT + tid;
-                REAL xp[NS], xn[NS], add[H], lwn;
+                REAL xp[NS], add[H];
 #pragma unroll
                 for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
-                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn, lwn, add);
-                const REAL aux = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[0]) : (REAL)0;
-                REAL sacc[H];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
+                aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
 #pragma unroll
-                for (int h = 0; h < H; ++h) sacc[h] = (REAL)0;
-                for (int j = 0; j < Nt; ++j) {
-                    int J = -1;
-                    for (int r = 0; r < R; ++r) {
-                        const bool pend = valid[k] && J < 0;
-                        if (!__any(pend)) break;
-                        double u1, u2;
+                for (int h = 0; h < H; ++h) sacc[k][h] = (REAL)0;
+                if (valid[k]) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                }
+            }
+            for (int j = 0; j < Nt; ++j) {
+                // ---- 2. accept-reject against the filter weights, R rounds per child ----------
+                int J[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) J[k] = -1;
+                // rounds outermost, slots innermost: PPT independent search chains in flight
+                for (int r = 0; r < R; ++r) {
+                    bool pend[PPT], anyp = false;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) { pend[k] = valid[k] && J[k] < 0; anyp = anyp || pend[k]; }
+                    if (!__any(anyp)) break;
+                    double u1[PPT], u2[PPT];
+                    int I[PPT];
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
                         if (RNG == PFG_RNG_REPLAY) {
                             const size_t at = (((size_t)t * Nt + j) * R + r) * N + own[k];
-                            u1 = pidx[at]; u2 = pacc[at];
-                        } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
-                        const int I = search_cdf(u1);
+                            u1[k] = pidx[at]; u2[k] = pacc[at];
+                        } else { u1[k] = u01_32(rng.next()); u2[k] = u01_32(rng.next()); }
+                        I[k] = 0;
+                    }
+#pragma unroll
+                    for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                        const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                        const int adv = step + (step >> 5);
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) I[k] += (cdf[I[k] + probe] <= u1[k]) ? adv : 0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        I[k] -= (I[k] * 993) >> 15;
+                        I[k] = I[k] < last ? I[k] : last;
                         REAL xI[NS];
 #pragma unroll
-                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NL + I];
-                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn));
-                        if (pend && u2 <= thr) J = I;
+                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NL + I[k]];
+                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn[k]));
+                        if (pend[k] && u2[k] <= thr) J[k] = I[k];
                     }
-                    if (valid[k] && J < 0) {
-                        // exact draw from softmax_k(logw_k + log q(child | x_k)): max, total, search
+                }
+                // ---- 3. children still pending: exact categorical draw, one child at a time, the
+                //         whole workgroup over the parents (max / scan / count, as the CDF build) ----
+                if (tid == 0) *qcount = 0;
+                __syncthreads();
+                int myslot[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    myslot[k] = -1;
+                    if (valid[k] && J[k] < 0) {
+                        const int i = k * NT + tid;
+                        myslot[k] = atomicAdd(qcount, 1);
+                        queue[myslot[k]] = i;
+                        // the child's fallback uniform rides in its (still unused) statistic slot
                         const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
                                                                   : u01_32(rng.next());
-                        REAL mx = -INFINITY;
-                        for (int q = 0; q < N; ++q) {
-                            REAL xq[NS];
-#pragma unroll
-                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
-                            const REAL l = lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn);
-                            mx = l > mx ? l : mx;
-                        }
-                        double tot = 0.0;
-                        for (int q = 0; q < N; ++q) {
-                            REAL xq[NS];
-#pragma unroll
-                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
-                            tot += (double)mth.exp((lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn)) - mx);
-                        }
-                        const double target = um * tot;
-                        double run = 0.0;
-                        J = last;
-                        for (int q = 0; q < N; ++q) {
-                            REAL xq[NS];
-#pragma unroll
-                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + q];
-                            run += (double)mth.exp((lwL[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xn)) - mx);
-                            if (run > target) { J = q; break; }
-                        }
+                        nxt[(size_t)NS * NL + i] = (REAL)um;
                     }
-                    J = J < 0 ? 0 : J;
+                }
+                __syncthreads();
+                const int nq = *qcount;
+                // one pending child per WAVE at a time: lane handles parents lane, lane+64, ...
+                // (wave-local max / total / ordered cumulative count: no workgroup barrier inside)
+                constexpr int MAXC = NT * PPT / WAVE;
+                const int nchunk = (N + WAVE - 1) / WAVE;
+                for (int e = wave; e < nq; e += NW) {
+                    const int ci = queue[e];
+                    REAL xc[NS];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NL + ci];
+                    const double um = (double)nxt[(size_t)NS * NL + ci];
+                    REAL l[MAXC];
+                    float mxf = -INFINITY;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        const int q = mI * WAVE + lane;
+                        const int qq = q < N ? q : last;
+                        REAL xq[NS];
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                        l[mI] = (q < N) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc) : (REAL)(-INFINITY);
+                        mxf = fmaxf(mxf, (float)l[mI]);
+                        if (mI + 1 >= nchunk) break;
+                    }
+                    const REAL mm = (REAL)wave_max(mxf);
+                    // chunk m = parents [64m, 64m+64): independent wave sums (pipelined), then the
+                    // chunk holding the target is scanned once -- index order as np.random.choice
+                    double ev[MAXC], csum[MAXC], tot = 0.0;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        ev[mI] = (mI < nchunk) ? (double)mth.exp((REAL)(l[mI] - mm)) : 0.0;
+                        csum[mI] = wave_sum(ev[mI]);
+                        tot += csum[mI];
+                    }
+                    const double target = um * tot;
+                    double before = 0.0, evsel = 0.0, run = 0.0;
+                    int msel = nchunk - 1;
+                    bool found = false;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        const bool here = !found && mI < nchunk && (run + csum[mI] > target || mI == nchunk - 1);
+                        if (here) { msel = mI; before = run; found = true; }
+                        evsel = here ? ev[mI] : evsel;
+                        run += csum[mI];
+                    }
+                    const double inc = wave_incl_scan(evsel) + before;
+                    int cnt = ((msel * WAVE + lane) < N && inc <= target) ? 1 : 0;
+                    cnt = msel * WAVE + (int)wave_sum((double)cnt);
+                    if (lane == 0) queue[e] = cnt < last ? cnt : last;      // result replaces the entry
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    if (myslot[k] >= 0) J[k] = queue[myslot[k]];
+                // ---- 4. rewired parent: stats[J] + w_t h(x_J, child) ----------------------------
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int Jk = J[k] < 0 ? 0 : J[k];
                     REAL xJ[NS], aj[H];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + J];
-                    additive_stat<MODEL, STAT, REAL>(c, xJ, xn, (REAL)y_t, aux, aj);
+                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + Jk];
+                    additive_stat<MODEL, STAT, REAL>(c, xJ, xn[k], (REAL)y_t, aux[k], aj);
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
                         const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
-                        sacc[h] += cur[(size_t)(NS + h) * NL + J] + a;
+                        sacc[k][h] += cur[(size_t)(NS + h) * NL + Jk] + a;
                     }
                 }
-                lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
+                __syncthreads();                // queue / statistic-slot scratch free for the next j
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
                 if (valid[k]) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
-#pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sacc[h] / (REAL)Nt;
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = sacc[k][h] / (REAL)Nt;
                 }
             }
         };

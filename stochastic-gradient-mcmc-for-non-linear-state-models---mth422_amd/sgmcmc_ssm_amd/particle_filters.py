@@ -109,8 +109,10 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         kwargs.pop("manual_sample_threshold", None)
         mar = kwargs.pop("max_accept_reject", None)
         paris_kw["Ntilde"] = int(kwargs.pop("Ntilde", 2))
-        paris_kw["max_accept_reject"] = int(100 * np.log10(int(N) / 10)) if mar is None else int(mar)
-        paris_kw["max_accept_reject"] = max(0, paris_kw["max_accept_reject"])
+        # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
+        # left (typically after 6-10 rounds) and draws those exactly; a fixed 16 rounds followed by
+        # the exact draw is the device equivalent (the reference's own cap is 100 log10(N/10))
+        paris_kw["max_accept_reject"] = 16 if mar is None else max(0, int(mar))
         pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
         if rng == "replay" and pools[2] is None:
             rng = "device"

@@ -56,3 +56,43 @@ if which == "mid":
                 run(f"svm T=300 N={N} {v} f32", "svm", 300, N, 256, steps=2, variant=v, dtype="f32")
             except Exception as e:
                 print(N, v, "failed", e)
+if which == "dropin":
+    # the reference-compatible Sampler API (REPLAY: host MT19937 streams + H2D), one chain
+    from sgmcmc_ssm_amd.models.svm import SVMSampler
+    np.random.seed(1)
+    p, gen = params("svm")
+    y = gen(T=1000, parameters=p)["observations"]
+    for kw, name in [(dict(subsequence_length=-1, buffer_length=-1), "full T=1000"),
+                     (dict(subsequence_length=16, buffer_length=4), "S=16 B=4"),
+                     (dict(subsequence_length=16, buffer_length=4, rng="device"), "S=16 B=4 device rng"),
+                     (dict(subsequence_length=-1, buffer_length=-1, rng="device"), "full T=1000 device rng"),
+                     (dict(subsequence_length=16, buffer_length=4, pf="paris"), "S=16 B=4 paris")]:
+        s = SVMSampler(n=1, m=1, observations=y, parameters=p.copy())
+        kw = dict(dict(kind="pf", pf="poyiadjis_N", N=1000), **kw)
+        s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
+        n = 20 if kw["subsequence_length"] == -1 else 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
+        dt = (time.perf_counter() - t0) / n
+        print(f"drop-in SVMSampler.sample_sgld N=1000 {name:28s}: {dt*1e3:8.3f} ms/step  {1/dt:8.1f} steps/s", flush=True)
+if which == "paris":
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.particle_filters import make_problem
+    ctx = _capi.default_context(0)
+    p, gen = params("svm"); np.random.seed(1); y = gen(T=1000, parameters=p)["observations"].reshape(-1)
+    for B, T in [(1, 24), (256, 24), (1, 1000), (256, 1000)]:
+        probs = [make_problem("svm", "prior", "paris", y[:T], p.theta(), 1000, prior_var=10.0, seed=1, stream=b) for b in range(B)]
+        ctx.run_batch(probs[:1]); t0 = time.perf_counter(); ctx.run_batch(probs); dt = time.perf_counter() - t0
+        print(f"paris svm N=1000 T={T} B={B}: {dt*1e3:.2f} ms  ({dt/T*1e6:.1f} us per timestep-batch)", flush=True)
+if which == "parisR":
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.particle_filters import make_problem
+    ctx = _capi.default_context(0)
+    p, gen = params("svm"); np.random.seed(1); y = gen(T=1000, parameters=p)["observations"].reshape(-1)
+    T = 200
+    for R in (0, 1, 2, 4, 8, 16, 32, 64):
+        for Nt in (1, 2):
+            probs = [make_problem("svm", "prior", "paris", y[:T], p.theta(), 1000, prior_var=10.0, seed=1, stream=b, max_accept_reject=R, Ntilde=Nt) for b in range(4)]
+            ctx.run_batch(probs[:1]); t0 = time.perf_counter(); ctx.run_batch(probs); dt = time.perf_counter() - t0
+            print(f"paris R={R} Ntilde={Nt}: {dt/T*1e6:.1f} us per timestep", flush=True)
