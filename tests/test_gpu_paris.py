@@ -95,3 +95,20 @@ def test_paris_through_sampler_api():
         sampler.noisy_gradient(kind="pf", pf="paris", N=5000)
     with pytest.raises(NotImplementedError):
         sampler.noisy_gradient(kind="pf", pf="poyiadjis_N2", N=100)
+
+
+def test_paris_f32_and_filter_stat(ctx):
+    """PaRIS with f32 state runs and agrees statistically with f64; suff-stat statistic works."""
+    from sgmcmc_ssm_amd.particle_filters import make_problem
+    p = default_params("lgssm")
+    np.random.seed(13)
+    y = GEN["lgssm"](T=25, parameters=p)["observations"].reshape(-1)
+    res = {}
+    for dtype in ("f64", "f32"):
+        probs = [make_problem("lgssm", "optimal", "paris", y, p.theta(), 200, prior_var=10.0, seed=3, stream=b,
+                              dtype=dtype, stat="suff") for b in range(256)]
+        outs = ctx.run_batch(probs)
+        res[dtype] = np.array([np.append(o["mean_stat"], o["loglik"]) for o in outs])
+        assert np.all(np.isfinite(res[dtype])) and res[dtype].shape[1] == 4
+    se = np.sqrt(res["f64"].var(axis=0) / 256 + res["f32"].var(axis=0) / 256)
+    assert np.all(np.abs(res["f64"].mean(axis=0) - res["f32"].mean(axis=0)) / se < 5.0)

@@ -209,3 +209,48 @@ def test_error_paths(ctx):
     with pytest.raises(ValueError):
         ctx.run_batch([q])
     assert ctx.run_batch([]) == []
+
+
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal")])
+def test_f32_teacher_forced_large_n_kernel(ctx, golden_trace, force_mem_kernel, model, kernel):
+    """f32 state in the large-N kernel (HBM scratch is f32 too), one reference step at a time."""
+    test_f32_teacher_forced(ctx, golden_trace, model, kernel)
+
+
+def test_edge_shapes(ctx):
+    """N = 1, T = 0, a window that accumulates nothing (t1 == tL) and a huge observation."""
+    rs = np.random.RandomState(5)
+    for N, T, t1, tL in [(1, 5, 0, 5), (1, 0, 0, 0), (64, 6, 3, 3), (65, 4, 0, 4)]:
+        y = rs.normal(size=T)
+        if T > 2:
+            y[1] = 40.0                      # extreme observation: weights collapse onto few particles
+        theta = [0.9, 1.3, 0.8]
+        z0, u, z = po.draw_streams(rs, N, T)
+        q = dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="replay", N=N,
+                 t1=t1, tL=tL, lambduh=1.0, prior_mean=0.0, prior_var=1.0, y=y, theta=theta, z0=z0, u=u, z=z)
+        o = ctx.run_batch([q], want_final=True)[0]
+        r = po.pf_window("svm", theta, y, N, z0, u, z, kernel="prior", pf="poyiadjis_N", stat="score", t1=t1, tL=tL,
+                         prior_mean=0.0, prior_var=1.0)
+        np.testing.assert_allclose(o["x_t"], r["x_t"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(o["mean_stat"], r["mean_statistic"], rtol=1e-8, atol=1e-8)
+        assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= 1e-8 * max(1.0, abs(r["loglikelihood_estimate"]))
+        if t1 == tL:
+            assert o["loglik"] == 0.0 and np.all(o["mean_stat"] == 0.0)
+
+
+def test_f32_whole_run_statistics(ctx):
+    """f32 state, device RNG, whole runs: mean score / log-likelihood agree with f64 runs within
+    5 standard errors (f32 cannot be compared seed by seed over long runs, SURVEY finding 2)."""
+    rs = np.random.RandomState(9)
+    T, N, B = 100, 500, 384
+    y = rs.normal(size=T) * 1.2
+    theta = [0.95, 1.4142, 1.4142]
+    def run(dtype, seed):
+        probs = [dict(model="svm", kernel="prior", dtype=dtype, rng="device", N=N, y=y, theta=theta, seed=seed,
+                      stream=b, prior_var=5.0) for b in range(B)]
+        outs = ctx.run_batch(probs)
+        return np.array([np.append(o["mean_stat"], o["loglik"]) for o in outs])
+    a, b = run("f64", 1), run("f32", 2)
+    se = np.sqrt(a.var(axis=0) / B + b.var(axis=0) / B)
+    zs = np.abs(a.mean(axis=0) - b.mean(axis=0)) / se
+    assert np.all(zs < 5.0), zs
