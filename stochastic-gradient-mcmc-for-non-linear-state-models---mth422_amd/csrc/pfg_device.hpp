@@ -1096,7 +1096,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
 // L2-resident (N = 10000 fp64 SVM: 2 x 320 KB ping-pong + 80 KB), every access by the owning
 // thread coalesced over the particle axis, only the parent gather random.  The timestep is
 // the same phase sequence as pf_reg_kernel with rolled loops over chunks of 1024 particles.
-//   scratch (REAL): lw[N] | buf0 {x[NS][N], stats[H][N]} | buf1 {...}
+//   scratch (REAL): lw[N] | buf0 [N][REC] | buf1 [N][REC],  record = {x[NS], stats[H], pad}
+// (array-of-records: the parent gather is ONE 16-byte-vector access per particle instead of NS+H
+// scattered 8-byte reads, each of which would pull its own cache line from L2)
 // ------------------------------------------------------------------------------------
 constexpr int MEM_NT = 1024;
 constexpr int MEM_NW = MEM_NT / WAVE;
@@ -1105,9 +1107,29 @@ constexpr int MEM_MAX_CHUNKS = MEM_MAX_N / MEM_NT;
 
 __host__ __device__ inline int mem_np2(int N) { int p = 64; while (p < N) p <<= 1; return p; }
 
+// record length in REALs: NS + H rounded up to whole 16-byte vectors
+template <int MODEL, typename REAL>
+__host__ __device__ constexpr int mem_rec_len() {
+    constexpr int per = 16 / (int)sizeof(REAL);
+    return (ModelDims<MODEL>::NS + ModelDims<MODEL>::H + per - 1) / per * per;
+}
 template <int MODEL, typename REAL>
 __host__ __device__ inline size_t mem_kernel_scratch_bytes(int N) {
-    return (size_t)N * (1 + 2 * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H)) * sizeof(REAL);
+    return (size_t)N * sizeof(REAL) * (1 + 2 * mem_rec_len<MODEL, REAL>()) + 16;
+}
+template <int REC, typename REAL>
+__device__ __forceinline__ void rec_load(REAL *dst, const REAL *src) {
+    using V = float4;
+#pragma unroll
+    for (int v = 0; v < REC * (int)sizeof(REAL) / 16; ++v)
+        reinterpret_cast<V *>(dst)[v] = reinterpret_cast<const V *>(src)[v];
+}
+template <int REC, typename REAL>
+__device__ __forceinline__ void rec_store(REAL *dst, const REAL *src) {
+    using V = float4;
+#pragma unroll
+    for (int v = 0; v < REC * (int)sizeof(REAL) / 16; ++v)
+        reinterpret_cast<V *>(dst)[v] = reinterpret_cast<const V *>(src)[v];
 }
 template <typename REAL, int RNG>
 __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
@@ -1148,9 +1170,11 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     double *red_W = red_S + PFG_MAX_STAT * NW;                      // [1] grand total (+ spare)
     double *tabmem = red_W + 8;
 
+    constexpr int REC = mem_rec_len<MODEL, REAL>();
     REAL *lwg = reinterpret_cast<REAL *>(P.scratch);                // [N]
-    REAL *cur = lwg + N;                                            // {x[NS][N], s[H][N]}
-    REAL *nxt = cur + (size_t)(NS + H) * N;
+    // records start 16-byte aligned behind the log-weights
+    REAL *cur = reinterpret_cast<REAL *>((reinterpret_cast<uintptr_t>(lwg + N) + 15) & ~(uintptr_t)15);   // [N][REC]
+    REAL *nxt = cur + (size_t)REC * N;
 
     Math<REAL, true> mth;
     mth.t.e2 = tabmem;
@@ -1191,10 +1215,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 x[0] = (REAL)(P.prior_mean + sd * z);
             }
             lwg[i] = l0;
+            alignas(16) REAL rec[REC] = {};
 #pragma unroll
-            for (int d = 0; d < NS; ++d) cur[(size_t)d * N + i] = x[d];
+            for (int d = 0; d < NS; ++d) rec[d] = x[d];
 #pragma unroll
-            for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * N + i] = s[h];
+            for (int h = 0; h < H; ++h) rec[NS + h] = s[h];
+            rec_store<REC, REAL>(cur + (size_t)i * REC, rec);
             if (P.trace_x) {
 #pragma unroll
                 for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
@@ -1241,7 +1267,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 p = v ? p : 0.0;
                 if (needS) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) part[h] += (double)cur[(size_t)(NS + h) * N + ii] * p;
+                    for (int h = 0; h < H; ++h) part[h] += (double)cur[(size_t)ii * REC + NS + h] * p;
                 }
                 const double inc = wave_incl_scan(p);
                 if (v) cdf[cdf_phys(i)] = inc;
@@ -1338,10 +1364,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                     tie = mg < tie ? mg : tie;
                 }
                 REAL xp[NS], sp[H], xn[NS], add[H], lwn;
+                alignas(16) REAL rec[REC];
+                rec_load<REC, REAL>(rec, cur + (size_t)a * REC);
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * N + a];
+                for (int d = 0; d < NS; ++d) xp[d] = rec[d];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sp[h] = cur[(size_t)(NS + h) * N + a];
+                for (int h = 0; h < H; ++h) sp[h] = rec[NS + h];
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z, xn, lwn, add);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
@@ -1352,9 +1380,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 if (v) {
                     lwg[i] = lwn;
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * N + i] = xn[d];
+                    for (int d = 0; d < NS; ++d) rec[d] = xn[d];
 #pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * N + i] = sp[h];
+                    for (int h = 0; h < H; ++h) rec[NS + h] = sp[h];
+                    rec_store<REC, REAL>(nxt + (size_t)i * REC, rec);
                     if (P.trace_x) {
                         const size_t row = (size_t)(t + 1) * N + i;
 #pragma unroll
@@ -1395,11 +1424,11 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     if (P.final_x) {
         for (int i = tid; i < N; i += NT) {
 #pragma unroll
-            for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * N + i];
+            for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)i * REC + d];
             if (P.final_logw) P.final_logw[i] = (double)lwg[i];
             if (P.final_stats && !is_filter) {
 #pragma unroll
-                for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * N + i];
+                for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)i * REC + NS + h];
             }
         }
     }

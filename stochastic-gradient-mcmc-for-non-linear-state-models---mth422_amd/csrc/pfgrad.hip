@@ -105,7 +105,9 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
 }
 
 size_t scratch_bytes(int model, int dtype, int N) {
-    return (size_t)N * (1 + 2 * (state_dim(model) + stat_dim(model))) * (dtype == PFG_F64 ? 8 : 4);
+    const size_t rs = dtype == PFG_F64 ? 8 : 4, per = 16 / rs;
+    const size_t rec = (state_dim(model) + stat_dim(model) + per - 1) / per * per;   // pfg::mem_rec_len
+    return (size_t)N * rs * (1 + 2 * rec) + 16;
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>

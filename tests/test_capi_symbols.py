@@ -44,7 +44,7 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"mem1024"
     assert lib.pfg_variant_name(0, 0, 0, 1, 10000) == b"mem1024" and lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"none"
     assert lib.pfg_scratch_bytes(0, 0, 1, 1000) == 0 and lib.pfg_scratch_bytes(0, 0, 1, 20000) == -1
-    assert lib.pfg_scratch_bytes(0, 0, 1, 10000) == (10000 * 9 * 8 + 255) // 256 * 256
+    assert lib.pfg_scratch_bytes(0, 0, 1, 10000) == (10000 * 9 * 8 + 16 + 255) // 256 * 256
 
 
 def test_no_cpu_fallback_without_gpu():
