@@ -167,6 +167,19 @@ def main():
         raise SystemExit("non-finite parameters after the run")
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # latency of ONE chain alone on the GPU (the reference's unit: one chain, one step at a time)
+    single = None
+    if rank == 0:
+        one = ChainEnsemble(args.model, y, p0, num_chains=1, N=N_PART, pf="poyiadjis_N", kernel=cfg["kernel"],
+                            epsilon=cfg["epsilon"], prior=prior, subsequence_length=cfg["S"],
+                            buffer_length=cfg["B"], dtype=args.dtype, seed=7, chain_offset=10 ** 6, device=dev_index)
+        one.step(2)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        one.step(5)
+        torch.cuda.synchronize(dev)
+        single = 5.0 / (time.perf_counter() - t1)
     window_T = T_SERIES if cfg["S"] == -1 else (cfg["S"] + 2 * cfg["B"])
     wsize = 8 if args.dtype == "f64" else 4
     bytes_per_pt = 2 * (cfg["n"] + 1 + cfg["h"]) * wsize
@@ -207,6 +220,7 @@ def main():
                 "parallelism": "independent chains, {0} GPU(s) x {1} chains, RCCL all_gather of samples".format(world, C),
             },
             "per_chain_steps_per_s": args.steps / elapsed,
+            "single_chain_alone_steps_per_s": single,
             "us_per_pf_timestep": kern_ms * 1e3 / window_T,
             "roofline": {
                 "bound": "hbm",
