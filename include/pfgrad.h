@@ -108,6 +108,8 @@ typedef struct pfg_result {
     double *trace_ll;   /* [T+1]        = 'all_loglikelihood_estimate'  */
     int32_t status;
     int32_t reserved;
+    int32_t *trace_anc; /* [T*N] ancestor index of every particle at every step (with trace_x):
+                           the genealogy, from which smoothed marginals are traced back */
 } pfg_result;
 
 /* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
@@ -133,6 +135,7 @@ typedef struct pfg_dev_problem {
     int32_t reserved;
     const double *paris_idx_u, *paris_acc_u, *paris_man_u;   /* PaRIS REPLAY pools (see pfg_problem) */
     int32_t Ntilde, max_accept_reject;
+    int32_t *trace_anc;      /* [T*N] or NULL */
 } pfg_dev_problem;
 
 int pfg_version(void);

@@ -345,7 +345,8 @@ def draw_streams(rng, N, T):
 def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
               lambduh=None, stat="score", t1=0, tL=None, weights=None,
               prior_mean=0.0, prior_var=1.0, save_all=False,
-              Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None):
+              Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None,
+              elementwise_statistic=False):
     """One buffered PF window.
 
     Args:
@@ -377,13 +378,18 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
     if model == "svm" and abs(d["A"]) > 1:
         raise ValueError("Current AR parameter is |A| = {0} > 1".format(abs(d["A"])))
     h = 3 if stat == "none" else STAT_DIM[(model, stat)]
+    h_base = h
+    if elementwise_statistic:
+        # elementwise_statistic_wrapper (buffered_smoother.py:64-65, 201-210): one h-block per
+        # window timestep, the block of step t sits at offset (t - t1) * h
+        h = (tL - t1) * h_base
 
     x = sample_x0(model, prior_mean, prior_var, z0)
     logw = np.zeros(N)
     loglik = 0.0
     stats = np.zeros(h) if is_filter else np.zeros((N, h))
     if save_all:
-        all_x, all_lw, all_s, all_ll = [x], [logw], [stats], [loglik]
+        all_x, all_lw, all_s, all_ll, all_anc = [x], [logw], [stats], [loglik], []
 
     for t in range(T):
         inside = (t >= t1) and (t < tL)
@@ -396,6 +402,8 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             S = np.sum(stats.T * log_normalize(logw), axis=1)
         # pf(): resample every step, propose, weight (pf.py:26-38)
         anc = multinomial_ancestors(log_normalize(logw), u[t])
+        if save_all:
+            all_anc.append(anc)
         parents = x[anc]
         x_next = kernel_rv(model, kernel, d, parents, y[t], z[t])
         new_logw = kernel_reweight(model, kernel, d, parents, x_next, y[t])
@@ -427,6 +435,10 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             add = sufficient_statistic(model, parents, x_next)
         else:
             add = np.zeros((N, h))      # zero_statistics (buffered_smoother.py:77-79)
+        if elementwise_statistic and inside and stat != "none":
+            wide = np.zeros((N, h))
+            wide[:, (t - t1) * h_base:(t - t1 + 1) * h_base] = add
+            add = wide
         add = add * weight_t            # additive_scale
 
         if is_filter:
@@ -454,7 +466,24 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         out["all_log_weights"] = np.array(all_lw)
         out["all_statistics"] = np.array(all_s)
         out["all_loglikelihood_estimate"] = np.array(all_ll)
+        out["all_ancestors"] = np.array(all_anc, dtype=int).reshape(-1, N)
     return out
+
+
+def latent_var_distr(model, theta, y, N, rng=np.random, **kw):
+    """Helper.pf_latent_var_distr (svm/helper.py:249-294, lgssm/helper.py:1145-1198,
+    garch/helper.py:274-318) for smoothing (lag=None): elementwise sufficient statistics,
+    averaged -> (x_mean (L,1), x_cov (L,1,1))."""
+    squared = kw.pop("squared", False)
+    out = pf_window_rng(model, theta, y, N, rng=rng, stat="suff", elementwise_statistic=True, **kw)
+    avg = np.reshape(out["mean_statistic"], (-1, 3))
+    if model == "garch" and squared:
+        x_mean = avg[:, 1]
+        x_cov = avg[:, 2] - x_mean ** 2
+    else:
+        x_mean = avg[:, 0]
+        x_cov = avg[:, 1] - x_mean ** 2
+    return np.reshape(x_mean, (x_mean.shape[0], 1)), np.reshape(x_cov, (x_cov.shape[0], 1, 1))
 
 
 def pf_window_rng(model, theta, y, N, rng=np.random, **kw):

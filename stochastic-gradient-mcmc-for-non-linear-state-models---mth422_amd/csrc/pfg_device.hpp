@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 if (valid[k]) {
                     const int i = k * NT + tid;
                     const size_t row = (size_t)(t + 1) * N + i;
+                    if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = anc[k];
 #pragma unroll
                     for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NL + i];
                     P.trace_logw[row] = (double)lw[k];
@@ -1386,6 +1387,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                     rec_store<REC, REAL>(nxt + (size_t)i * REC, rec);
                     if (P.trace_x) {
                         const size_t row = (size_t)(t + 1) * N + i;
+                        if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = a;
 #pragma unroll
                         for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)xn[d];
                         P.trace_logw[row] = (double)lwn;

@@ -515,6 +515,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (r.trace_logw) n_out += (size_t)(q.T + 1) * q.N;
         if (r.trace_stats) n_out += (size_t)(q.T + 1) * q.N * H;
         if (r.trace_ll) n_out += (size_t)q.T + 1;
+        if (r.trace_anc) n_out += ((size_t)q.T * q.N + 1) / 2;       /* int32 pairs in f64 slots */
+        if (r.trace_anc && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_anc needs trace_x");
         if ((r.logw_T || r.stats_T) && !r.x_T) return fail(ctx, PFG_ERR_INVALID, id + "logw_T/stats_T need x_T");
         if ((r.trace_logw == nullptr) != (r.trace_x == nullptr))
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
@@ -600,6 +602,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.trace_logw = take(r.trace_logw != nullptr, (size_t)(q.T + 1) * q.N);
         d.trace_stats = take(r.trace_stats != nullptr, (size_t)(q.T + 1) * q.N * H);
         d.trace_ll = take(r.trace_ll != nullptr, (size_t)q.T + 1);
+        d.trace_anc = reinterpret_cast<int32_t *>(take(r.trace_anc != nullptr, ((size_t)q.T * q.N + 1) / 2));
         d.step_ctr = nullptr;
         d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
                               : nullptr;
@@ -639,6 +642,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         fetch(r.trace_logw, d.trace_logw, (size_t)(q.T + 1) * q.N);
         fetch(r.trace_stats, d.trace_stats, (size_t)(q.T + 1) * q.N * H);
         fetch(r.trace_ll, d.trace_ll, (size_t)q.T + 1);
+        if (r.trace_anc && d.trace_anc)
+            std::memcpy(r.trace_anc, host_of(reinterpret_cast<const double *>(d.trace_anc)), (size_t)q.T * q.N * 4);
         r.status = PFG_OK;
     }
     return PFG_OK;

@@ -49,6 +49,7 @@ class Result(C.Structure):
         ("x_T", _dp), ("logw_T", _dp), ("stats_T", _dp),
         ("trace_x", _dp), ("trace_logw", _dp), ("trace_stats", _dp), ("trace_ll", _dp),
         ("status", C.c_int32), ("reserved", C.c_int32),
+        ("trace_anc", C.POINTER(C.c_int32)),
     ]
 
 
@@ -75,6 +76,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("smoother", "i4"), ("stat", "i4"), ("flags", "u4"), ("reserved", "i4"),
     ("paris_idx_u", "u8"), ("paris_acc_u", "u8"), ("paris_man_u", "u8"),
     ("Ntilde", "i4"), ("max_accept_reject", "i4"),
+    ("trace_anc", "u8"),
 ], align=True)
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
@@ -269,6 +271,8 @@ class Context:
                 o["all_x_t"] = np.zeros((T + 1, N, ns))
                 o["all_log_weights"] = np.zeros((T + 1, N))
                 o["all_loglikelihood_estimate"] = np.zeros(T + 1)
+                o["all_ancestors"] = np.zeros((T, N), dtype=np.int32)
+                r.trace_anc = o["all_ancestors"].ctypes.data_as(C.POINTER(C.c_int32))
                 r.trace_x, r.trace_logw = _ptr(o["all_x_t"]), _ptr(o["all_log_weights"])
                 r.trace_ll = _ptr(o["all_loglikelihood_estimate"])
                 if not is_filter:

@@ -190,3 +190,37 @@ def average_statistic(out):
     p = np.exp(lw - np.max(lw))
     p /= np.sum(p)
     return np.sum(out["statistics"].T * p, axis=1)
+
+
+def smoothed_sufficient_statistics(model, all_x_t, all_ancestors, log_weights, t1, tL, weights=None):
+    """Per-timestep sufficient statistics along every surviving particle's lineage.
+
+    With pf='poyiadjis_N' (lambda = 1) the reference's `elementwise_statistic=True` run
+    (buffered_smoother.py:64-65, 201-210) copies the parent's whole statistic vector at every step
+    and fills in block t with h_t(x_t, x_{t+1}); the final per-particle vector is therefore just
+    h_t evaluated along that particle's ancestry.  The kernel records the genealogy
+    (`all_ancestors[t, i]` = parent of particle i at step t) and the particles; tracing it back
+    costs O(N (tL - t1)) instead of the reference's O(N (tL - t1)^2) copies.
+
+    Returns (statistics [N, 3 (tL - t1)], mean_statistic [3 (tL - t1)]) exactly as
+    out['statistics'] / average_statistic(out) of the reference."""
+    T, N = all_ancestors.shape
+    L = tL - t1
+    stats = np.zeros((N, 3 * L))
+    idx = np.arange(N)
+    for t in range(T - 1, -1, -1):
+        parents = all_ancestors[t][idx]
+        if t1 <= t < tL:
+            x_next = all_x_t[t + 1][idx]
+            x_prev = all_x_t[t][parents]
+            if model == "garch":
+                x1 = x_next[:, 0]
+                h = np.array([x1, x1 ** 2, x1 ** 4]).T
+            else:
+                h = np.hstack([x_next, x_next ** 2, x_prev * x_next])
+            w = 1.0 if weights is None else weights[t - t1]
+            stats[:, 3 * (t - t1):3 * (t - t1 + 1)] = h * w
+        idx = parents
+    p = np.exp(log_weights - np.max(log_weights))
+    p /= np.sum(p)
+    return stats, np.sum(stats.T * p, axis=1)

@@ -149,6 +149,42 @@ class PFHelper(object):
         return _pf.run_windows([q])[0]["loglikelihood_estimate"]
 
 
+    def pf_latent_var_distr(self, observations, parameters, lag=None, subsequence_start=0,
+                            subsequence_end=None, weights=None, pf="poyiadjis_N", N=1000, kernel=None,
+                            forward_message=None, squared=False, **kwargs):
+        """Smoothed marginals of the latent state on [subsequence_start, subsequence_end):
+        (x_mean (L,1), x_cov (L,1,1)) -- svm/helper.py:249-294, lgssm/helper.py:1145-1198,
+        garch/helper.py:274-318.  The particle filter runs on the GPU with genealogy recording; the
+        per-timestep statistics are traced back along the lineages (particle_filters.
+        smoothed_sufficient_statistics).  lag=None with pf='poyiadjis_N' only: the reference's
+        lag=0 / pf='filter' branch fails in average_statistic (shape mismatch), and
+        nemeth / paris with elementwise statistics are not built."""
+        if lag == 0 and pf != 'filter':
+            raise ValueError("pf must be filter for lag = 0")
+        elif lag is None and pf == 'filter':
+            raise ValueError("pf must not be filter for smoothing")
+        elif lag is not None and lag != 0:
+            raise NotImplementedError("lag can only be None or 0")
+        if pf != "poyiadjis_N":
+            raise NotImplementedError("pf_latent_var_distr on the HIP backend supports pf='poyiadjis_N' "
+                                      "(got '{0}')".format(pf))
+        kwargs.pop("tqdm", None)
+        q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
+                            pf, N, kernel, forward_message, stat="none", **kwargs)
+        o = _capi.default_context().run_batch([q], want_trace=True)[0]
+        _pf._recycle_streams([q])
+        T = q["y"].shape[0]
+        tL = T if subsequence_end is None else subsequence_end
+        _, avg = _pf.smoothed_sufficient_statistics(self.model, o["all_x_t"], o["all_ancestors"],
+                                                    o["log_weights"], subsequence_start, tL, weights)
+        avg = np.reshape(avg, (-1, 3))
+        if self.model == "garch" and squared:
+            x_mean, x_cov = avg[:, 1], avg[:, 2] - avg[:, 1] ** 2
+        else:
+            x_mean, x_cov = avg[:, 0], avg[:, 1] - avg[:, 0] ** 2
+        return np.reshape(x_mean, (x_mean.shape[0], 1)), np.reshape(x_cov, (x_cov.shape[0], 1, 1))
+
+
 # ----------------------------------------------------------------------------------------
 # Sampler
 # ----------------------------------------------------------------------------------------
@@ -543,9 +579,22 @@ class SGMCMCSampler(object):
             tqdm_iter=tqdm_iter, catch_interrupt=catch_interrupt, **kwargs)
         return plist['parameters'].tolist(), times['time'].tolist()
 
-    # -- out of scope on this backend -------------------------------------------------------------------
-    def predict(self, *args, **kwargs):
-        raise NotImplementedError("predict / pf_latent_var_distr is a 'next' row (SURVEY.md 8f)")
+    # -- predict (kind='pf', latent marginals) ---------------------------------------------------------
+    def predict(self, target='latent', distr=None, lag=None, return_distr=None, num_samples=None,
+                kind='pf', observations=None, parameters=None, **kwargs):
+        """Smoothed latent marginals by particle filter (sgmcmc_sampler.py:956-1069, kind='pf',
+        target='latent', return_distr=True): -> (x_mean, x_cov) from Helper.pf_latent_var_distr."""
+        self._require_pf(kind)
+        if target != 'latent':
+            raise NotImplementedError("predict(target='{0}', kind='pf') is not built (pf_y_distr)".format(target))
+        if return_distr is False:
+            raise ValueError("return_distr must be True for kind = pf")
+        observations = self._get_observations(observations)
+        if parameters is None:
+            parameters = self.parameters
+        kwargs.pop('tqdm', None)
+        return self.message_helper.pf_latent_var_distr(lag=lag, observations=observations,
+                                                       parameters=parameters, **kwargs)
 
     def exact_loglikelihood(self, *args, **kwargs):
         raise NotImplementedError(_ONLY_PF.format('marginal'))
@@ -569,6 +618,21 @@ class SeqSGMCMCSampler(object):
                     super()._check_observation_shape(observations=observation)
                 except ValueError as e:
                     raise ValueError("Error in observations[{0}] :\n{1}".format(ii, e))
+
+    def predict(self, target='latent', distr=None, lag=None, return_distr=None, num_samples=None,
+                kind='pf', observations=None, parameters=None, tqdm=None, **kwargs):
+        """One (x_mean, x_cov) per sequence (sgmcmc_sampler.py:1285-1423, kind='pf')."""
+        self._require_pf(kind)
+        if target != 'latent':
+            raise NotImplementedError("predict(target='{0}', kind='pf') is not built (pf_y_distr)".format(target))
+        if return_distr is False:
+            raise ValueError("return_distr must be True for kind = pf")
+        observations = self._get_observations(observations)
+        if parameters is None:
+            parameters = self.parameters
+        return [self.message_helper.pf_latent_var_distr(lag=lag, observations=observation,
+                                                        parameters=parameters, **kwargs)
+                for observation in observations]
 
     def _choose_sequences(self, observations, num_sequences):
         indices = np.arange(len(observations))

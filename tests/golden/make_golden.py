@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -409,6 +409,41 @@ def make_paris_fixtures():
     np.savez_compressed(os.path.join(HERE, "paris.npz"), **out)
 
 
+def make_latent_fixtures():
+    """Helper.pf_latent_var_distr (smoothed marginals via elementwise statistics)."""
+    out, meta = {}, []
+    helpers = dict(svm=SVMHelper, garch=GARCHHelper, lgssm=LGSSMHelper)
+    for ci, (model, kernel, pf, N, T, t1, tL) in enumerate([
+            ("svm", None, "poyiadjis_N", 200, 30, 0, None), ("svm", "prior", "poyiadjis_N", 64, 20, 4, 16),
+            ("lgssm", None, "poyiadjis_N", 150, 25, 0, None), ("lgssm", "prior", "poyiadjis_N", 100, 18, 2, 18),
+            ("garch", None, "poyiadjis_N", 120, 22, 0, None), ("garch", "prior", "poyiadjis_N", 80, 16, 3, 12)]):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(900 + ci)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        fm = data["initial_message"] if model != "garch" else None
+        helper = helpers[model](forward_message=fm, **({} if model == "garch" else p.dim))
+        seed = 9100 + ci
+        np.random.seed(seed)
+        x_mean, x_cov = helper.pf_latent_var_distr(observations=y, parameters=p, subsequence_start=t1,
+                                                   subsequence_end=tL, pf=pf, N=N, kernel=kernel)
+        key = "l{0}".format(ci)
+        pm, pv = prior_x(model, p, data)
+        meta.append(dict(key=key, model=model, kernel=kernel, pf=pf, N=N, T=T, t1=t1, tL=tL, seed=seed,
+                         prior_mean=pm, prior_var=pv))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        out[key + "/x_mean"], out[key + "/x_cov"] = x_mean, x_cov
+        if model == "garch":
+            np.random.seed(seed)
+            xm2, xc2 = helper.pf_latent_var_distr(observations=y, parameters=p, subsequence_start=t1,
+                                                  subsequence_end=tL, pf=pf, N=N, kernel=kernel, squared=True)
+            out[key + "/x_mean_sq"], out[key + "/x_cov_sq"] = xm2, xc2
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "latent.npz"), **out)
+
+
 def make_ksd_fixtures():
     """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
     from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
@@ -438,6 +473,8 @@ if __name__ == "__main__":
         make_ksd_fixtures()
     if only in ("", "paris"):
         make_paris_fixtures()
-    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz"):
+    if only in ("", "latent"):
+        make_latent_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
