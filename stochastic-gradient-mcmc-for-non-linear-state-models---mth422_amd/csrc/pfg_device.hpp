@@ -1,10 +1,14 @@
 // Device code of libpfgrad: one persistent workgroup runs one whole buffered particle-filter
-// window (the T-loop of particle_filters/buffered_smoother.py:93-133) in a single launch,
-// particle state resident in registers + LDS.  gfx950 only (wave64, 160 KiB LDS).
+// window (the T-loop of particle_filters/buffered_smoother.py:93-133) in a single launch.
+// gfx950 only (wave64, DPP row_bcast, 160 KiB LDS).
+//   pf_reg_kernel   N <= 1024: particles / statistics / CDF in LDS, log-weights in registers
+//   pf_mem_kernel   N <= 16384: CDF in LDS, particle records in an L2-resident HBM scratch
 //
 // Compiled with -ffp-contract=off: the f64 instantiation follows the reference's NumPy
-// expression order operation by operation so that REPLAY runs agree with the reference to
-// rounding of exp/log and of the (parallel) weight sum / prefix scan only.
+// expression order operation by operation, so REPLAY runs differ from the reference only by
+// the rounding of exp / log (LDS-table forms, <= 2 ulp), of the shift used by log_normalize
+// (f32-rounded maximum, mathematically immaterial) and of the parallel weight sum / prefix
+// scan.  Where this file wants a fused multiply-add it says fma().
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,14 +69,9 @@ __device__ __forceinline__ double wave_max(double v) {
 #undef PFG_MAX_STEP
     return bcast_lane63(v);
 }
-// Upper bound of the wave's maximum, reduced in f32 (v_max_f32 takes DPP operands directly:
-// 6 instructions instead of ~50 for f64).  The shift used by log_normalize only has to be
-// within a few ulp(f32) of the true maximum: exp(lw - m) and m + log(W/N) are invariant to it
-// up to rounding.
-__device__ __forceinline__ float max_shift_f32(double v) {
-    float f = (float)v;                                  // round to nearest
-    return f;
-}
+// The shift m used by log_normalize is reduced in f32 (v_max_f32 takes DPP operands directly:
+// 6 instructions instead of ~50 for f64).  It only has to be within a few ulp(f32) of the true
+// maximum: exp(lw - m) / sum and m + log(W/N) are invariant to it up to rounding.
 __device__ __forceinline__ float wave_max(float v) {
 #define PFG_MAX_STEP(CTRL, RM) { float o = dpp_f32<CTRL, RM>(v, v); v = o > v ? o : v; }
     PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)

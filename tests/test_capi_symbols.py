@@ -57,3 +57,37 @@ def test_no_cpu_fallback_without_gpu():
     assert "oracle" not in " ".join(open(os.path.join(os.path.dirname(_capi.__file__), f)).read()
                                     for f in os.listdir(os.path.dirname(_capi.__file__)) if f.endswith(".py")
                                     ).replace("oracle fixtures", "")
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_gpu(tmp_path):
+    """The same C program on an MI355X: pfg_create + pfg_run succeed from plain C."""
+    out = _build_and_run_c_consumer(tmp_path)
+    assert "run rc=0" in out, out
+
+
+def test_plain_c_consumer(tmp_path):
+    """include/pfgrad.h compiles as C99 with gcc and a C program links against libpfgrad.so
+    (without a GPU it must report the missing device loudly)."""
+    out = _build_and_run_c_consumer(tmp_path)
+    assert "run rc=0" in out or "create failed as expected" in out, out
+
+
+def _build_and_run_c_consumer(tmp_path):
+    import shutil
+    import subprocess
+    if _build.is_stale():
+        _build.build_library()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.dirname(_build.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-o", exe,
+           "-L", libdir, "-lpfgrad", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    return run.stdout
