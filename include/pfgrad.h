@@ -71,6 +71,10 @@ enum pfg_status {
 
 /* flags of pfg_problem / pfg_dev_problem */
 #define PFG_FLAG_GARCH_STATIONARY_PRIOR 1u /* prior_var = alpha/(1-beta-gamma) (garch/helper.py:324-327) */
+/* EXTENSION (not in the reference, which resamples multinomially every step, pf.py:26-30):
+ * systematic resampling, u_i = (i + u0)/N with ONE uniform u0 per timestep.  DEVICE rng only;
+ * parity-unpinned, checked statistically. */
+#define PFG_FLAG_SYSTEMATIC_RESAMPLING 2u
 
 /* One buffered PF window, host side (all pointers are HOST pointers, C-contiguous f64). */
 typedef struct pfg_problem {

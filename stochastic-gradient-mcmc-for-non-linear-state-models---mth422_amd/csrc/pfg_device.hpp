@@ -552,6 +552,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     double *red_max = red + PPT * NW;       // [NW]
     float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;           // [H*NW]
+    double *red_W0 = red_S + PFG_MAX_STAT * NW;      // [8] spare doubles (systematic-resampling offset)
+    const bool systematic = (P.flags & PFG_FLAG_SYSTEMATIC_RESAMPLING) != 0;
+    const double invN = 1.0 / (double)N;
     double *tabmem = red + RegLayout<NT, PPT>::RED;
     REAL *lwL = reinterpret_cast<REAL *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8);    // [NL], PARIS only
     int *paris_queue = reinterpret_cast<int *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8 + NL);   // [NL], PARIS only
@@ -685,6 +688,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
             cs[k] = wave_incl_scan(cs[k]);
             if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
         }
+        if (RNG != PFG_RNG_REPLAY && systematic && tid == 0) red_W0[0] = u01_32(rng.next());
         // this step's randomness: REPLAY loads are issued here so that their latency overlaps the
         // barrier; device draws happen right before their use (keeps register pressure down)
         double uu[PPT];
@@ -768,8 +772,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
         // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
         if (RNG != PFG_RNG_REPLAY) {
+            if (systematic) {
+                // extension: one uniform per timestep (drawn by thread 0 before barrier 2)
+                const double u0 = red_W0[0];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
+                for (int k = 0; k < PPT; ++k) uu[k] = ((double)(k * NT + tid) + u0) * invN;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
+            }
         }
         int anc[PPT];
 #pragma unroll

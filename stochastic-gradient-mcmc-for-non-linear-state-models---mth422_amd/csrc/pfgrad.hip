@@ -491,6 +491,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (rng == PFG_RNG_REPLAY && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
         if (rng == PFG_RNG_REPLAY && q.T > 0 && (!q.u || !q.z)) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs u and z");
         if (q.init_x && !q.init_logw) return fail(ctx, PFG_ERR_INVALID, id + "init_x needs init_logw");
+        if ((q.flags & PFG_FLAG_SYSTEMATIC_RESAMPLING) && (rng != PFG_RNG_DEVICE || q.N > 1024))
+            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "systematic resampling needs the DEVICE rng and N <= 1024");
         if (!(q.prior_var >= 0.0) && !(q.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR) && !q.init_x)
             return fail(ctx, PFG_ERR_INVALID, id + "prior_var must be >= 0");
         if (model == PFG_MODEL_SVM && std::fabs(q.theta[0]) > 1.0) {

@@ -17,6 +17,7 @@ STAT = {"score": 0, "suff": 1, "none": 2}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
+FLAG_SYSTEMATIC_RESAMPLING = 2
 MAX_STAT, MAX_THETA, OUT_DOUBLES = 4, 4, 8
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}

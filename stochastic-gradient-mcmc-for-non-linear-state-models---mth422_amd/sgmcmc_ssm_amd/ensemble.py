@@ -67,12 +67,13 @@ class ChainEnsemble(object):
       subsequence_length S / buffer_length B: -1 = full sequence (no window sampling)
       dtype: 'f64' | 'f32' particle-state arithmetic;  seed: Philox key
       chain_offset: global index of this rank's first chain (keeps streams distinct across GPUs)
+      resampling: 'multinomial' (the reference's) | 'systematic' (extension, parity-unpinned)
     """
 
     def __init__(self, model, observations, parameters, num_chains=None, N=1000, pf="poyiadjis_N",
                  lambduh=None, kernel=None, epsilon=0.1, prior=None, subsequence_length=-1,
                  buffer_length=-1, dtype="f64", seed=0, chain_offset=0, device=None,
-                 forward_message=None, partition_style=None):
+                 forward_message=None, partition_style=None, resampling="multinomial"):
         if not torch.cuda.is_available():
             raise RuntimeError("ChainEnsemble needs an MI355X (no CPU fallback)")
         Parameters, Prior, Helper = _model_info(model)
@@ -142,6 +143,12 @@ class ChainEnsemble(object):
         d["smoother"], d["stat"] = _capi.SMOOTHER["nemeth"], _capi.STAT["score"]
         if model == "garch" and self.helper.default_forward_message is None:
             d["flags"] = _capi.FLAG_GARCH_STATIONARY_PRIOR
+        if resampling == "systematic":       # extension, see include/pfgrad.h
+            if self.N > 1024:
+                raise NotImplementedError("systematic resampling is built for N <= 1024")
+            d["flags"] |= _capi.FLAG_SYSTEMATIC_RESAMPLING
+        elif resampling != "multinomial":
+            raise ValueError("Unrecognized resampling = {0}".format(resampling))
         sb = self.ctx.scratch_bytes(model, dtype, "device", self.N)
         if sb < 0:
             raise ValueError("N = {0} is above the supported maximum".format(self.N))

@@ -88,6 +88,14 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
     kwargs = dict(kwargs)
     kwargs.pop("tqdm", None)
     kwargs.pop("tqdm_name", None)
+    resampling = kwargs.pop("resampling", "multinomial")
+    if resampling == "systematic":
+        # extension (the reference only resamples multinomially): one uniform per timestep
+        if rng == "replay":
+            raise ValueError("resampling='systematic' needs rng='device' (no reference stream to replay)")
+        flags = int(flags) | _capi.FLAG_SYSTEMATIC_RESAMPLING
+    elif resampling != "multinomial":
+        raise ValueError("Unrecognized resampling = {0}".format(resampling))
     smoother, lambduh = _smoother_of(pf, kwargs)
     y = np.ascontiguousarray(observations, dtype=float)
     if y.ndim == 2:
