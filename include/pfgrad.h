@@ -50,7 +50,12 @@ enum pfg_kernel { PFG_KERNEL_PRIOR = 0, PFG_KERNEL_OPTIMAL = 1 };
 /* smoothers: particle_filters/pf.py:138-181 (nemeth; poyiadjis_N = lambduh 1.0), :40-82 (filter),
  * :183-341 (PaRIS: Ntilde backward-sampled parents per child by accept-reject, exact
  * categorical fallback after max_accept_reject rounds; N <= 1024) */
-enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTHER_PARIS = 2 };
+enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTHER_PARIS = 2,
+                    /* EXTENSION (not in the reference, which resamples multinomially every step,
+                     * pf.py:26-30): NEMETH with systematic resampling, u_i = (i + u0)/N with ONE
+                     * uniform u0 per timestep.  DEVICE rng, N <= 1024; parity-unpinned, checked
+                     * statistically.  Its own kernel instantiation (keeps the hot path untouched). */
+                    PFG_SMOOTHER_NEMETH_SYSTEMATIC = 3 };
 /* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
 enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2 };
 /* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
@@ -71,10 +76,6 @@ enum pfg_status {
 
 /* flags of pfg_problem / pfg_dev_problem */
 #define PFG_FLAG_GARCH_STATIONARY_PRIOR 1u /* prior_var = alpha/(1-beta-gamma) (garch/helper.py:324-327) */
-/* EXTENSION (not in the reference, which resamples multinomially every step, pf.py:26-30):
- * systematic resampling, u_i = (i + u0)/N with ONE uniform u0 per timestep.  DEVICE rng only;
- * parity-unpinned, checked statistically. */
-#define PFG_FLAG_SYSTEMATIC_RESAMPLING 2u
 
 /* One buffered PF window, host side (all pointers are HOST pointers, C-contiguous f64). */
 typedef struct pfg_problem {
@@ -166,8 +167,8 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 /* as pfg_launch_device for a batch whose descriptors all have smoother = `smoother`
- * (PFG_SMOOTHER_PARIS needs its own kernel variant and LDS budget; the plain entry point
- * serves NEMETH / FILTER) */
+ * (PFG_SMOOTHER_PARIS and PFG_SMOOTHER_NEMETH_SYSTEMATIC have their own kernel instantiations;
+ * the plain entry point serves NEMETH / FILTER) */
 int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
                                int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 /* bytes of per-problem HBM scratch (pfg_dev_problem.scratch, 256-byte aligned) the large-N

@@ -18,6 +18,8 @@
 namespace pfg {
 
 constexpr int WAVE = 64;
+// kernel instantiation modes beyond the plain filter / Nemeth path
+constexpr int MODE_PLAIN = 0, MODE_PARIS = 1, MODE_SYSTEMATIC = 2;
 constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
 
 // ------------------------------------------------------------------------------------
@@ -494,8 +496,9 @@ template <int NT, int PPT> struct RegLayout {
 
 // PP variants: cdf has NT*PPT entries (tail = sentinel 2.0 -> unrolled, clamp-free search) and
 // the fp64 math runs on LDS tables; the single-buffer variant spends its LDS on particles.
-template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool PARIS = false>
+template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
+    constexpr bool PARIS = (MODE == MODE_PARIS);
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
     constexpr bool FAST = fast_layout(NT, PP);
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
@@ -514,9 +517,12 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP)
     return (NT == 256 && PPT == 4 && !PP) ? 3 : 1;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool PARIS = false>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+    constexpr bool PARIS = (MODE == MODE_PARIS);
+    constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
     static_assert(!PARIS || PP, "PaRIS needs the parents intact while children are built: ping-pong buffers");
+    static_assert(!systematic || RNG == PFG_RNG_DEVICE, "systematic resampling draws its offset on the device");
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NW = NT / WAVE;
@@ -553,7 +559,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;           // [H*NW]
     double *red_W0 = red_S + PFG_MAX_STAT * NW;      // [8] spare doubles (systematic-resampling offset)
-    const bool systematic = (P.flags & PFG_FLAG_SYSTEMATIC_RESAMPLING) != 0;
     const double invN = 1.0 / (double)N;
     double *tabmem = red + RegLayout<NT, PPT>::RED;
     REAL *lwL = reinterpret_cast<REAL *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8);    // [NL], PARIS only

@@ -135,8 +135,8 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
 int launch_paris_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, true>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, true>(n_max);
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>(n_max);
     if (lds > kLdsLimit)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
     if (lds > 64 * 1024) {
@@ -155,7 +155,23 @@ int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
     return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
 }
 
-constexpr int kVariantParis = -3;
+constexpr int kVariantParis = -3, kVariantSystematic = -4;
+
+// systematic-resampling instantiation (extension): device RNG, the fp64 / f32 default 256x4 variants
+template <int MODEL, int KERNEL, typename REAL, bool PP>
+int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max > 1024) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling is built for N <= 1024");
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>(n_max);
+    if (lds > kLdsLimit) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling: state does not fit LDS");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
 
 template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
@@ -174,6 +190,11 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 template <int MODEL, int KERNEL>
 int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
               hipStream_t st) {
+    if (v == kVariantSystematic) {
+        if (rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
+        if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
+        return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
+    }
     if (v == kVariantParis) {
         if (dtype == PFG_F64) {
             if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
@@ -215,7 +236,9 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
-    int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis : pick_variant(model, dtype, rng, n_max);
+    int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis
+            : smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC ? kVariantSystematic
+            : pick_variant(model, dtype, rng, n_max);
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
@@ -404,7 +427,7 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
                                int B, const pfg_dev_problem *dev_probs, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_smoother: dev_probs is NULL");
-    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_PARIS)
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_NEMETH_SYSTEMATIC)
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother);
@@ -475,7 +498,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (q.N < 1) return fail(ctx, PFG_ERR_INVALID, id + "N must be >= 1");
         if (q.T < 0) return fail(ctx, PFG_ERR_INVALID, id + "T must be >= 0");
         if (q.t1 < 0 || q.tL < q.t1) return fail(ctx, PFG_ERR_INVALID, id + "need 0 <= t1 <= tL");
-        if (q.smoother < PFG_SMOOTHER_NEMETH || q.smoother > PFG_SMOOTHER_PARIS)
+        if (q.smoother < PFG_SMOOTHER_NEMETH || q.smoother > PFG_SMOOTHER_NEMETH_SYSTEMATIC)
             return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
         if ((q.smoother == PFG_SMOOTHER_PARIS) != (ps[0].smoother == PFG_SMOOTHER_PARIS))
             return fail(ctx, PFG_ERR_INVALID, id + "pf = 'paris' cannot share a batch with other smoothers");
@@ -491,7 +514,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (rng == PFG_RNG_REPLAY && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
         if (rng == PFG_RNG_REPLAY && q.T > 0 && (!q.u || !q.z)) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs u and z");
         if (q.init_x && !q.init_logw) return fail(ctx, PFG_ERR_INVALID, id + "init_x needs init_logw");
-        if ((q.flags & PFG_FLAG_SYSTEMATIC_RESAMPLING) && (rng != PFG_RNG_DEVICE || q.N > 1024))
+        if ((q.smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC) != (ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC))
+            return fail(ctx, PFG_ERR_INVALID, id + "systematic resampling cannot share a batch with other smoothers");
+        if (q.smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC && (rng != PFG_RNG_DEVICE || q.N > 1024))
             return fail(ctx, PFG_ERR_UNSUPPORTED, id + "systematic resampling needs the DEVICE rng and N <= 1024");
         if (!(q.prior_var >= 0.0) && !(q.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR) && !q.init_x)
             return fail(ctx, PFG_ERR_INVALID, id + "prior_var must be >= 0");
@@ -525,7 +550,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
     const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
-    const int variant = paris ? kVariantParis : pick_variant(model, dtype, rng, n_max);
+    const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
+    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic : pick_variant(model, dtype, rng, n_max);
     if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
@@ -620,7 +646,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
     rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
-                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : PFG_SMOOTHER_NEMETH);
+                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC : PFG_SMOOTHER_NEMETH);
     if (rc) return rc;
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));

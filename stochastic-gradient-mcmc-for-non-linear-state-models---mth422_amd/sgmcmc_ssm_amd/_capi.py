@@ -12,12 +12,11 @@ from . import _build
 # ---- enums (include/pfgrad.h) ---------------------------------------------------------
 MODEL = {"svm": 0, "garch": 1, "lgssm": 2}
 KERNEL = {"prior": 0, "optimal": 1}
-SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2}
+SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2, "nemeth_systematic": 3}
 STAT = {"score": 0, "suff": 1, "none": 2}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
-FLAG_SYSTEMATIC_RESAMPLING = 2
 MAX_STAT, MAX_THETA, OUT_DOUBLES = 4, 4, 8
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
@@ -95,7 +94,8 @@ class PfgError(RuntimeError):
 
 
 def library_path():
-    return _build.LIB_PATH
+    """In-tree csrc/libpfgrad.so; PFGRAD_LIB=<path> substitutes another build (A/B timing)."""
+    return os.environ.get("PFGRAD_LIB") or _build.LIB_PATH
 
 
 def load_library():
@@ -296,6 +296,11 @@ class Context:
     def stream(self):
         """The context's own hipStream_t (as an integer handle)."""
         return self.lib.pfg_ctx_stream(self.handle) or 0
+
+    def launch_device_smoother(self, model, kernel, dtype, rng, smoother, n_max, B, dev_probs_ptr, stream_ptr=0):
+        self._check(self.lib.pfg_launch_device_smoother(
+            self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], SMOOTHER[smoother], int(n_max),
+            int(B), C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
 
     def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=0):
         """stream_ptr: a hipStream_t handle used as is (0 = HIP's default stream, which is also

@@ -90,6 +90,7 @@ class ChainEnsemble(object):
             raise ValueError("ChainEnsemble supports pf = 'poyiadjis_N' | 'nemeth', got {0}".format(pf))
         self.P = _capi.THETA_DIM[model]
         self._Parameters = Parameters
+        self.resampling = resampling
 
         y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
         self.T = y.shape[0]
@@ -146,7 +147,7 @@ class ChainEnsemble(object):
         if resampling == "systematic":       # extension, see include/pfgrad.h
             if self.N > 1024:
                 raise NotImplementedError("systematic resampling is built for N <= 1024")
-            d["flags"] |= _capi.FLAG_SYSTEMATIC_RESAMPLING
+            d["smoother"] = _capi.SMOOTHER["nemeth_systematic"]
         elif resampling != "multinomial":
             raise ValueError("Unrecognized resampling = {0}".format(resampling))
         sb = self.ctx.scratch_bytes(model, dtype, "device", self.N)
@@ -220,8 +221,12 @@ class ChainEnsemble(object):
         """Enqueue one particle-filter launch for all chains on `stream` (default: torch's
         current stream).  Results land in self.out_dev[C, 8] (score columns, loglik)."""
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        self.ctx.launch_device(self.model, self.kernel, self.dtype, "device", self.N, self.C,
-                               self.desc_dev.data_ptr(), st)
+        if self.resampling == "systematic":
+            self.ctx.launch_device_smoother(self.model, self.kernel, self.dtype, "device", "nemeth_systematic",
+                                            self.N, self.C, self.desc_dev.data_ptr(), st)
+        else:
+            self.ctx.launch_device(self.model, self.kernel, self.dtype, "device", self.N, self.C,
+                                   self.desc_dev.data_ptr(), st)
 
     def launch_update(self, stream=None):
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream

@@ -93,10 +93,13 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         # extension (the reference only resamples multinomially): one uniform per timestep
         if rng == "replay":
             raise ValueError("resampling='systematic' needs rng='device' (no reference stream to replay)")
-        flags = int(flags) | _capi.FLAG_SYSTEMATIC_RESAMPLING
     elif resampling != "multinomial":
         raise ValueError("Unrecognized resampling = {0}".format(resampling))
     smoother, lambduh = _smoother_of(pf, kwargs)
+    if resampling == "systematic":
+        if smoother != "nemeth":
+            raise NotImplementedError("systematic resampling is built for pf = 'poyiadjis_N' | 'nemeth'")
+        smoother = "nemeth_systematic"
     y = np.ascontiguousarray(observations, dtype=float)
     if y.ndim == 2:
         if y.shape[1] != 1:
