@@ -196,6 +196,16 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
                            uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr,
                            void *hip_stream);
 
+/* EXTENSION (not in the reference: its samplers are SGD / ADAGRAD / SGLD / SGRLD / Gibbs,
+ * sgmcmc_sampler.py:467-648): SGHMC update with friction alpha in (0, 1] for resident chains,
+ *   v <- (1 - alpha) v + eps (grad_logprior + ghat)/Tscale + N(0, 2 alpha eps / Tscale),  theta <- theta + v,
+ * then project_parameters.  momentum [B][PFG_MAX_THETA] is updated in place; alpha = 1 is exactly
+ * pfg_sgld_update_device (same noise stream).  Parity-unpinned. */
+int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum,
+                            const double *outs, const pfg_prior_hyper *hyper, double epsilon, double alpha,
+                            double Tscale, uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr,
+                            void *hip_stream);
+
 /* Inverse-multiquadric kernel Stein discrepancy of K points x[K][d] with score estimates
  * g[K][d] (HOST pointers, d <= 8): sqrt(sum_{i,j} k0(x_i,x_j)) / K for
  * k(x,y) = (c^2 + |x-y|^2)^(-beta) -- IMQ_KSD of sgmcmc_ssm/trace_metric_functions.py:20-81

@@ -254,10 +254,12 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
 // ---- SGLD update for resident chains ---------------------------------------------------
 __device__ __forceinline__ double reflect_chol(double L) { return L < 0.0 ? sqrt(L * L + 1e-16) : L; }
 
+// momentum == nullptr: SGLD.  Otherwise SGHMC with friction alpha: the increment d of each
+// variable becomes v <- (1 - alpha) v + drift + sqrt(alpha) * noise (noise ~ N(0, 2 eps / T)).
 __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
                                    const double *__restrict__ outs, pfg_prior_hyper hy, double eps,
                                    double Tscale, uint64_t seed, uint64_t chain_offset,
-                                   const uint64_t *step_ctr) {
+                                   const uint64_t *step_ctr, double *__restrict__ momentum, double alpha) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double *th = theta + (size_t)b * PFG_MAX_THETA;
@@ -267,7 +269,16 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
     const uint32_t c1 = (uint32_t)step, c2 = (uint32_t)(step >> 32) ^ (uint32_t)(gid >> 32);
     pfg::u32x4 r0 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A11u}, (uint32_t)seed, (uint32_t)(seed >> 32));
     pfg::u32x4 r1 = pfg::philox4x32_10({(uint32_t)gid, c1, c2, 0x5A12u}, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps);
+    const double nsd = sqrt(1.0 / Tscale) * sqrt(2.0 * eps) * (momentum ? sqrt(alpha) : 1.0);
+    double *mv = momentum ? momentum + (size_t)b * PFG_MAX_THETA : nullptr;
+    // one variable's increment: SGLD drift + noise, or the SGHMC momentum recursion
+    auto incr = [&](int slot, double drift, double noise) {
+        const double d = drift + noise;
+        if (!mv) return d;
+        const double v = (1.0 - alpha) * mv[slot] + d;
+        mv[slot] = v;
+        return v;
+    };
     double nz[4];
     const pfg::Math<double, false> mth = {};
     mth.normal_pair(r0.x, r0.y, nz[0], nz[1]);
@@ -284,10 +295,10 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
         double pA = -1.0 * (Qinv * (A - hy.mean_A)) / hy.var_col_A;
         double pC = -1.0 * (Rinv * (C - hy.mean_C)) / hy.var_col_C;
         int j = 0;
-        A += eps * ((pA + gA) / Tscale) + nsd * nz[j++];
-        if (lg) C += eps * ((pC + gC) / Tscale) + nsd * nz[j++];
-        LQ += eps * ((pLQ + gLQ) / Tscale) + nsd * nz[j++];
-        LR += eps * ((pLR + gLR) / Tscale) + nsd * nz[j++];
+        A += incr(0, eps * ((pA + gA) / Tscale), nsd * nz[j]); ++j;
+        if (lg) { C += incr(1, eps * ((pC + gC) / Tscale), nsd * nz[j]); ++j; }
+        LQ += incr(lg ? 2 : 1, eps * ((pLQ + gLQ) / Tscale), nsd * nz[j]); ++j;
+        LR += incr(lg ? 3 : 2, eps * ((pLR + gLR) / Tscale), nsd * nz[j]); ++j;
         // project_parameters: _utils.py:165-170, covariance.py:68-80, lgssm/parameters.py:39-42
         double aa = fabs(A);
         if (aa > 0.9999) A *= 0.9999 / aa;
@@ -304,10 +315,10 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
         double p2 = ((hy.alpha_lambduh - 1.0) / (1.0 + lam) - (hy.beta_lambduh - 1.0) / (1.0 - lam)) * lam * (1.0 - lam);
         double pLR = (hy.df_Rinv - 2.0) / LR - LR / hy.scale_Rinv;
         // score columns [LR, log_mu, logit_phi, logit_lambduh]
-        lmu += eps * ((p0 + g[1]) / Tscale) + nsd * nz[0];
-        lphi += eps * ((p1 + g[2]) / Tscale) + nsd * nz[1];
-        llam += eps * ((p2 + g[3]) / Tscale) + nsd * nz[2];
-        LR += eps * ((pLR + g[0]) / Tscale) + nsd * nz[3];
+        lmu += incr(0, eps * ((p0 + g[1]) / Tscale), nsd * nz[0]);
+        lphi += incr(1, eps * ((p1 + g[2]) / Tscale), nsd * nz[1]);
+        llam += incr(2, eps * ((p2 + g[3]) / Tscale), nsd * nz[2]);
+        LR += incr(3, eps * ((pLR + g[0]) / Tscale), nsd * nz[3]);
         th[0] = lmu; th[1] = lphi; th[2] = llam; th[3] = reflect_chol(LR);
     }
 }
@@ -433,10 +444,22 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother);
 }
 
+int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum, const double *outs,
+                            const pfg_prior_hyper *hyper, double epsilon, double alpha, double Tscale,
+                            uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream);
+
 int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const double *outs,
                            const pfg_prior_hyper *hyper, double epsilon, double Tscale, uint64_t seed,
                            uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream) {
+    return pfg_sghmc_update_device(ctx, model, B, theta, nullptr, outs, hyper, epsilon, 1.0, Tscale, seed,
+                                   chain_offset, step_ctr, hip_stream);
+}
+
+int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum, const double *outs,
+                            const pfg_prior_hyper *hyper, double epsilon, double alpha, double Tscale,
+                            uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
+    if (!(alpha > 0.0 && alpha <= 1.0)) return fail(ctx, PFG_ERR_INVALID, "SGHMC friction alpha must be in (0, 1]");
     if (!theta || !outs || !hyper) return fail(ctx, PFG_ERR_INVALID, "pfg_sgld_update_device: NULL argument");
     if (model < 0 || model > 2) return fail(ctx, PFG_ERR_INVALID, "Unrecognized model id");
     if (!(epsilon > 0.0) || !(Tscale > 0.0)) return fail(ctx, PFG_ERR_INVALID, "epsilon and Tscale must be > 0");
@@ -444,7 +467,7 @@ int pfg_sgld_update_device(pfg_ctx *ctx, int model, int B, double *theta, const 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(sgld_update_kernel, dim3((B + 127) / 128), dim3(128), 0, st, model, B, theta, outs,
-                       *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr);
+                       *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr, momentum, alpha);
     if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;

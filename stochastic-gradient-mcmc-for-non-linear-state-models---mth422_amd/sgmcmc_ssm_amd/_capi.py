@@ -81,7 +81,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
-           "pfg_sgld_update_device", "pfg_imq_ksd")
+           "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd")
 
 _lib = None
 
@@ -153,6 +153,10 @@ def load_library():
                                            C.POINTER(PriorHyper), C.c_double, C.c_double, C.c_uint64,
                                            C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pfg_sgld_update_device.restype = C.c_int
+    lib.pfg_sghmc_update_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(PriorHyper), C.c_double, C.c_double, C.c_double,
+                                            C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.pfg_sghmc_update_device.restype = C.c_int
     lib.pfg_imq_ksd.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp]
     lib.pfg_imq_ksd.restype = C.c_int
     _lib = lib
@@ -328,6 +332,14 @@ class Context:
         self._check(self.lib.pfg_imq_ksd(self.handle, x.shape[0], x.shape[1], _ptr(x), _ptr(g), float(c),
                                          float(beta), C.byref(out)))
         return float(out.value)
+
+    def sghmc_update_device(self, model, B, theta_ptr, momentum_ptr, outs_ptr, hyper, epsilon, alpha, Tscale, seed,
+                            chain_offset=0, step_ctr_ptr=None, stream_ptr=0):
+        self._check(self.lib.pfg_sghmc_update_device(
+            self.handle, MODEL[model], int(B), C.c_void_p(theta_ptr), C.c_void_p(momentum_ptr), C.c_void_p(outs_ptr),
+            C.byref(hyper), float(epsilon), float(alpha), float(Tscale), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            C.c_uint64(int(chain_offset)), C.c_void_p(step_ctr_ptr) if step_ctr_ptr else None,
+            C.c_void_p(int(stream_ptr))))
 
     def variant_name(self, model, kernel, dtype, rng, n_max):
         return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()

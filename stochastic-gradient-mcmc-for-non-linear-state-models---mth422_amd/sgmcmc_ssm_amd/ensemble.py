@@ -68,12 +68,15 @@ class ChainEnsemble(object):
       dtype: 'f64' | 'f32' particle-state arithmetic;  seed: Philox key
       chain_offset: global index of this rank's first chain (keeps streams distinct across GPUs)
       resampling: 'multinomial' (the reference's) | 'systematic' (extension, parity-unpinned)
+      sampler: 'sgld' (sample_sgld + project_parameters) | 'sghmc' (extension: momentum with
+               friction `friction` in (0,1]; friction = 1 is SGLD)
     """
 
     def __init__(self, model, observations, parameters, num_chains=None, N=1000, pf="poyiadjis_N",
                  lambduh=None, kernel=None, epsilon=0.1, prior=None, subsequence_length=-1,
                  buffer_length=-1, dtype="f64", seed=0, chain_offset=0, device=None,
-                 forward_message=None, partition_style=None, resampling="multinomial"):
+                 forward_message=None, partition_style=None, resampling="multinomial",
+                 sampler="sgld", friction=0.1):
         if not torch.cuda.is_available():
             raise RuntimeError("ChainEnsemble needs an MI355X (no CPU fallback)")
         Parameters, Prior, Helper = _model_info(model)
@@ -91,6 +94,9 @@ class ChainEnsemble(object):
         self.P = _capi.THETA_DIM[model]
         self._Parameters = Parameters
         self.resampling = resampling
+        if sampler not in ("sgld", "sghmc"):
+            raise ValueError("sampler must be 'sgld' or 'sghmc'")
+        self.sampler, self.friction = sampler, float(friction)
 
         y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
         self.T = y.shape[0]
@@ -122,6 +128,7 @@ class ChainEnsemble(object):
         self.theta_dev = torch.from_numpy(th).to(dev)
         self.out_dev = torch.zeros((self.C, _capi.OUT_DOUBLES), dtype=torch.float64, device=dev)
         self.step_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.momentum_dev = torch.zeros((self.C, _capi.MAX_THETA), dtype=torch.float64, device=dev)
         self.weights_dev = None
         self._weights_table = None
         if S > 0:
@@ -230,9 +237,15 @@ class ChainEnsemble(object):
 
     def launch_update(self, stream=None):
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        self.ctx.sgld_update_device(self.model, self.C, self.theta_dev.data_ptr(), self.out_dev.data_ptr(),
-                                    self.hyper, self.epsilon, float(self.T), self.seed ^ 0x5DEECE66D,
-                                    self.chain_offset, self.step_ctr.data_ptr(), st)
+        if self.sampler == "sghmc":
+            self.ctx.sghmc_update_device(self.model, self.C, self.theta_dev.data_ptr(), self.momentum_dev.data_ptr(),
+                                         self.out_dev.data_ptr(), self.hyper, self.epsilon, self.friction,
+                                         float(self.T), self.seed ^ 0x5DEECE66D, self.chain_offset,
+                                         self.step_ctr.data_ptr(), st)
+        else:
+            self.ctx.sgld_update_device(self.model, self.C, self.theta_dev.data_ptr(), self.out_dev.data_ptr(),
+                                        self.hyper, self.epsilon, float(self.T), self.seed ^ 0x5DEECE66D,
+                                        self.chain_offset, self.step_ctr.data_ptr(), st)
 
     def step(self, num_steps=1):
         """num_steps x (sample_sgld + project_parameters) for every chain.  Asynchronous."""
@@ -243,6 +256,40 @@ class ChainEnsemble(object):
             self.launch_pf()
             self.launch_update()
             self.steps_done += 1
+
+    def run(self, num_steps, thin=1):
+        """num_steps steps, keeping every `thin`-th state: returns ndarray [num_steps // thin, C, P].
+        Samples are staged in HBM and copied to the host once at the end."""
+        keep = num_steps // thin
+        buf = torch.empty((max(keep, 1), self.C, self.P), dtype=torch.float64, device=self.device)
+        k = 0
+        for it in range(1, num_steps + 1):
+            self.step(1)
+            if it % thin == 0 and k < keep:
+                buf[k].copy_(self.theta_dev[:, :self.P])
+                k += 1
+        return buf[:keep].cpu().numpy()
+
+    # -- checkpoint / resume (the reference checkpoints parameters with joblib around its fit loop,
+    #    svm/driver.py:362-408; here the whole ensemble state is a few small arrays) -------------
+    def state_dict(self):
+        self.synchronize()
+        return dict(theta=self.theta_dev.cpu().numpy(), momentum=self.momentum_dev.cpu().numpy(),
+                    step_ctr=int(self.step_ctr.item()), steps_done=int(self.steps_done),
+                    host_rng=self._host_rng.get_state(), seed=self.seed, chain_offset=self.chain_offset,
+                    model=self.model, N=self.N, C=self.C)
+
+    def load_state_dict(self, state):
+        for key in ("model", "N", "C", "seed", "chain_offset"):
+            if state[key] != getattr(self, key):
+                raise ValueError("checkpoint {0} = {1} does not match the ensemble ({2})".format(
+                    key, state[key], getattr(self, key)))
+        self.theta_dev.copy_(torch.from_numpy(np.ascontiguousarray(state["theta"])))
+        self.momentum_dev.copy_(torch.from_numpy(np.ascontiguousarray(state["momentum"])))
+        self.step_ctr.fill_(int(state["step_ctr"]))
+        self.steps_done = int(state["steps_done"])
+        self._host_rng.set_state(state["host_rng"])
+        self.synchronize()
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
