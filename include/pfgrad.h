@@ -33,6 +33,7 @@ extern "C" {
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
+#define PFG_MAX_PRED 16          /* predictive log-likelihood leads k = 0..num_steps_ahead (<= 15) */
 
 typedef struct pfg_ctx pfg_ctx;
 
@@ -57,7 +58,11 @@ enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTH
                      * statistically.  Its own kernel instantiation (keeps the hot path untouched). */
                     PFG_SMOOTHER_NEMETH_SYSTEMATIC = 3 };
 /* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
-enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2 };
+enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2,
+                /* k-step-ahead predictive log-likelihoods accumulated with the filter's
+                 * logsumexp update (pf.py:72-76; statistic functions svm/helper.py:352-395,
+                 * lgssm/helper.py:1281-1336, garch/helper.py:374-412).  FILTER smoother only. */
+                PFG_STAT_PREDICTIVE = 3 };
 /* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
 enum pfg_dtype { PFG_F64 = 0, PFG_F32 = 1 };
 /* REPLAY: caller supplies the NumPy legacy stream (z0[N], u[T*N], z[T*N]) -> results
@@ -98,6 +103,10 @@ typedef struct pfg_problem {
      * paris_man_u [T][Ntilde][N] (fallback draw); NULL with the DEVICE rng. */
     int32_t Ntilde, max_accept_reject;
     const double *paris_idx_u, *paris_acc_u, *paris_man_u;
+    /* PFG_STAT_PREDICTIVE only: leads 0..num_steps_ahead; REPLAY pool of the standard normals the
+     * statistic draws, pred_z [T][num_steps_ahead+1][N] (SVM, GARCH; unused for LGSSM). */
+    int32_t num_steps_ahead, reserved2;
+    const double *pred_z;
 } pfg_problem;
 
 /* Result of one window; optional arrays are caller-allocated HOST buffers or NULL. */
@@ -115,6 +124,7 @@ typedef struct pfg_result {
     int32_t reserved;
     int32_t *trace_anc; /* [T*N] ancestor index of every particle at every step (with trace_x):
                            the genealogy, from which smoothed marginals are traced back */
+    double pred[PFG_MAX_PRED]; /* PFG_STAT_PREDICTIVE: out['statistics'][k] of the reference */
 } pfg_result;
 
 /* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
@@ -141,6 +151,10 @@ typedef struct pfg_dev_problem {
     const double *paris_idx_u, *paris_acc_u, *paris_man_u;   /* PaRIS REPLAY pools (see pfg_problem) */
     int32_t Ntilde, max_accept_reject;
     int32_t *trace_anc;      /* [T*N] or NULL */
+    const double *pred_z;    /* PREDICTIVE, REPLAY: [T][num_steps_ahead+1][N] */
+    double *pred_out;        /* PREDICTIVE: [PFG_MAX_PRED] */
+    void *pred_scratch;      /* PREDICTIVE: [N][PFG_MAX_PRED] of the state type */
+    int32_t num_steps_ahead, reserved3;
 } pfg_dev_problem;
 
 int pfg_version(void);

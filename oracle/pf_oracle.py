@@ -317,6 +317,57 @@ def paris_backward_indices(model, d, x, logw, x_next, Ntilde, draws, t,
     return J
 
 
+def predictive_statistic(model, d, x_next, t, y_all, num_steps_ahead, normals):
+    """[log Pr(y_{t+k} | x_{t+1-ish})]_{k=0..K} per particle -> (N, K+1).
+    svm_predictive_loglikelihood (svm/helper.py:352-395, Ntilde = 1),
+    gaussian_predictive_loglikelihood (lgssm/helper.py:1281-1336, n = m = 1),
+    garch_predictive_loglikelihood (garch/helper.py:374-412).
+    `normals(k)` returns the N standard normals the reference draws at lead k (SVM: the Monte-Carlo
+    sample, drawn even at k = 0 where its scale is 0; GARCH: prior_kernel.rv; LGSSM: none)."""
+    N = x_next.shape[0]
+    T = y_all.shape[0]
+    K = num_steps_ahead
+    out = np.zeros((N, K + 1))
+    if model == "svm":
+        x_pred_mean = x_next + 0.0
+        x_pred_cov = 0.0
+        R, Q = d["R"], d["Q"]
+        for k in range(K + 1):
+            if t + k >= T:
+                break
+            diff = y_all[t + k]
+            x_mc = (np.outer(x_pred_mean, np.ones(1)) + np.sqrt(x_pred_cov) * normals(k).reshape(N, 1))
+            y_pred_cov = R * np.exp(x_mc)
+            out[:, k] = np.mean(-0.5 * diff ** 2 / y_pred_cov + -0.5 * LOG_2PI - 0.5 * np.log(y_pred_cov), axis=1)
+            x_pred_mean = d["A"] * x_pred_mean
+            x_pred_cov = Q + d["A"] ** 2 * x_pred_cov
+    elif model == "lgssm":
+        x_pred_mean = x_next + 0.0
+        x_pred_cov = np.zeros((1, 1))
+        R, Q = d["R"], d["Q"]
+        for k in range(K + 1):
+            if t + k >= T:
+                break
+            diff = (np.outer(np.ones(N), y_all[t + k]) - np.dot(x_pred_mean, d["C"].T))
+            y_pred_cov = R + np.dot(d["C"], np.dot(x_pred_cov, d["C"].T))
+            pl = -0.5 * diff ** 2 / y_pred_cov + -0.5 * LOG_2PI - 0.5 * np.log(y_pred_cov)
+            out[:, k] = pl[:, 0]
+            x_pred_mean = np.dot(x_pred_mean, d["A"].T)
+            x_pred_cov = Q + np.dot(d["A"], np.dot(x_pred_cov, d["A"].T))
+    else:
+        x_pred = x_next + 0
+        R = d["R"]
+        for k in range(K + 1):
+            if t + k >= T:
+                break
+            diff = np.ones(N) * y_all[t + k] - x_pred[:, 0]
+            y_pred_cov = R
+            pl = -0.5 * diff ** 2 / y_pred_cov + -0.5 * LOG_2PI - 0.5 * np.log(y_pred_cov)
+            out[:, k] = pl
+            x_pred = kernel_rv("garch", "prior", d, x_pred, None, normals(k))
+    return out
+
+
 STAT_DIM = {
     ("svm", "score"): 3, ("lgssm", "score"): 4, ("garch", "score"): 4,
     ("svm", "suff"): 3, ("lgssm", "suff"): 3, ("garch", "suff"): 3,
@@ -346,7 +397,7 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
               lambduh=None, stat="score", t1=0, tL=None, weights=None,
               prior_mean=0.0, prior_var=1.0, save_all=False,
               Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None,
-              elementwise_statistic=False):
+              elementwise_statistic=False, num_steps_ahead=5, pred_normals=None):
     """One buffered PF window.
 
     Args:
@@ -377,7 +428,13 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
     d = derived(model, theta)
     if model == "svm" and abs(d["A"]) > 1:
         raise ValueError("Current AR parameter is |A| = {0} > 1".format(abs(d["A"])))
-    h = 3 if stat == "none" else STAT_DIM[(model, stat)]
+    if stat == "predictive":
+        # pf_predictive_loglikelihood_estimate: filter + logsumexp accumulation (pf.py:72-76)
+        if pf != "filter":
+            raise ValueError("Only can use pf = 'filter' since we are filtering")
+        h = num_steps_ahead + 1
+    else:
+        h = 3 if stat == "none" else STAT_DIM[(model, stat)]
     h_base = h
     if elementwise_statistic:
         # elementwise_statistic_wrapper (buffered_smoother.py:64-65, 201-210): one h-block per
@@ -429,7 +486,9 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             if save_all:
                 all_x.append(x); all_lw.append(logw); all_s.append(stats); all_ll.append(loglik)
             continue
-        if inside and stat == "score":
+        if inside and stat == "predictive":
+            add = predictive_statistic(model, d, x_next, t, y, num_steps_ahead, lambda k: pred_normals(t, k))
+        elif inside and stat == "score":
             add = score_statistic(model, d, parents, x_next, y[t])
         elif inside and stat == "suff":
             add = sufficient_statistic(model, parents, x_next)
@@ -441,7 +500,14 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             add = wide
         add = add * weight_t            # additive_scale
 
-        if is_filter:
+        if is_filter and stat == "predictive":
+            # pf.py:72-76 (logsumexp=True).  NB the reference's np.sum has NO axis: the sum runs
+            # over every lead k AND every particle, and its log is added to every column (so
+            # steps outside the window, where add = 0, add log(K+1)).  Reproduced as is.
+            max_add = np.max(add.T, axis=1)
+            stats = stats + max_add + np.log(np.sum(
+                np.exp(add.T - max_add[:, np.newaxis]) * log_normalize(new_logw)))
+        elif is_filter:
             # pf.py:78-80, new weights
             stats = stats + np.sum(add.T * log_normalize(new_logw), axis=1)
         else:
@@ -528,6 +594,20 @@ def pf_loglikelihood_estimate(model, theta, y, N, rng=np.random, **kw):
     """Helper.pf_loglikelihood_estimate."""
     out = pf_window_rng(model, theta, y, N, rng=rng, stat="suff", **kw)
     return out["loglikelihood_estimate"]
+
+
+def pf_predictive_loglikelihood_estimate(model, theta, y, N, rng=np.random, num_steps_ahead=5, **kw):
+    """Helper.pf_predictive_loglikelihood_estimate (svm/helper.py:187-247, garch/helper.py:172-231,
+    lgssm/helper.py:1048-1087), consuming `rng` in the reference's order: per timestep N uniforms,
+    N normals (pf()), then inside the window N normals per lead k (SVM / GARCH)."""
+    z0 = rng.normal(size=N)
+    out = pf_window(model, theta, y, N, z0, _LazyStreams(rng, N, "u"), _LazyStreams(rng, N, "z"), pf="filter",
+                    stat="predictive", num_steps_ahead=num_steps_ahead,
+                    pred_normals=(lambda t, k: rng.normal(size=N)) if model != "lgssm" else (lambda t, k: None),
+                    **kw)
+    pred = np.array(out["statistics"], dtype=float)
+    pred[0] = out["loglikelihood_estimate"]
+    return pred
 
 
 def garch_prior_x(theta):

@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -444,6 +444,37 @@ def make_latent_fixtures():
     np.savez_compressed(os.path.join(HERE, "latent.npz"), **out)
 
 
+def make_predictive_fixtures():
+    """Helper.pf_predictive_loglikelihood_estimate of the three models."""
+    out, meta = {}, []
+    helpers = dict(svm=SVMHelper, garch=GARCHHelper, lgssm=LGSSMHelper)
+    for ci, (model, kernel, N, T, t1, tL, K) in enumerate([
+            ("svm", None, 100, 20, 0, None, 5), ("svm", "prior", 64, 14, 3, 11, 3),
+            ("lgssm", None, 100, 20, 0, None, 5), ("lgssm", "prior", 50, 12, 2, 12, 10),
+            ("garch", None, 100, 20, 0, None, 5), ("garch", "prior", 70, 15, 4, 13, 2)]):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(1200 + ci)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        fm = data["initial_message"] if model != "garch" else None
+        helper = helpers[model](forward_message=fm, **({} if model == "garch" else p.dim))
+        seed = 9500 + ci
+        np.random.seed(seed)
+        pred = helper.pf_predictive_loglikelihood_estimate(observations=y, parameters=p, num_steps_ahead=K,
+                                                           subsequence_start=t1, subsequence_end=tL, N=N,
+                                                           kernel=kernel)
+        key = "q{0}".format(ci)
+        pm, pv = prior_x(model, p, data)
+        meta.append(dict(key=key, model=model, kernel=kernel, N=N, T=T, t1=t1, tL=tL, K=K, seed=seed,
+                         prior_mean=pm, prior_var=pv))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        out[key + "/pred"] = np.asarray(pred, dtype=float)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "predictive.npz"), **out)
+
+
 def make_ksd_fixtures():
     """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
     from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
@@ -475,6 +506,8 @@ if __name__ == "__main__":
         make_paris_fixtures()
     if only in ("", "latent"):
         make_latent_fixtures()
-    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz"):
+    if only in ("", "predictive"):
+        make_predictive_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

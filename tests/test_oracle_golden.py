@@ -112,3 +112,18 @@ def test_paris_oracle_bit_exact():
         for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
             assert np.array_equal(np.asarray(out[name], dtype=float), g.get(key, name)), (meta, name)
         assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic"))
+
+
+def test_predictive_oracle_bit_exact():
+    """Predictive log-likelihood restatement (filter + logsumexp, model-specific k-step statistics)
+    vs the reference, consuming the legacy stream in the reference's order."""
+    from conftest import Golden
+    g = Golden("predictive.npz")
+    assert len(g.meta) == 6
+    for m in g.meta:
+        kernel = m["kernel"] or po.DEFAULT_KERNEL[m["model"]]
+        rng = np.random.RandomState(m["seed"])
+        pred = po.pf_predictive_loglikelihood_estimate(
+            m["model"], g.get(m["key"], "theta"), g.get(m["key"], "y"), m["N"], rng=rng, num_steps_ahead=m["K"],
+            kernel=kernel, t1=m["t1"], tL=m["tL"], prior_mean=m["prior_mean"], prior_var=m["prior_var"])
+        assert np.array_equal(pred, g.get(m["key"], "pred")), (m, pred, g.get(m["key"], "pred"))
