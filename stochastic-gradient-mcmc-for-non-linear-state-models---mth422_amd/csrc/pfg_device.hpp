@@ -1151,7 +1151,7 @@ template <typename REAL, int RNG>
 __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
     const size_t np2 = (size_t)mem_np2(N);
     return (np2 + np2 / 32) * 8 + (size_t)(2 * MEM_MAX_CHUNKS * MEM_NW + MEM_NW + PFG_MAX_STAT * MEM_NW + 8) * 8 +
-           tab_bytes<REAL, RNG, true>();
+           (size_t)(PFG_MAX_PRED * MEM_NW + MEM_NW + 2 * PFG_MAX_PRED) * 8 + tab_bytes<REAL, RNG, true>();
 }
 
 template <int MODEL, int KERNEL, typename REAL, int RNG>
@@ -1184,13 +1184,25 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;                                   // [H*NW]
     double *red_W = red_S + PFG_MAX_STAT * NW;                      // [1] grand total (+ spare)
-    double *tabmem = red_W + 8;
+    // predictive log-likelihood (PFG_STAT_PREDICTIVE): column maxima, weighted sum, accumulators
+    double *red_pmax = red_W + 8;                                   // [MAX_PRED][NW]
+    double *red_pt = red_pmax + PFG_MAX_PRED * NW;                  // [NW]
+    double *pmaxv = red_pt + NW;                                    // [MAX_PRED] column maxima
+    double *predv = pmaxv + PFG_MAX_PRED;                           // [MAX_PRED] out['statistics']
+    double *tabmem = predv + PFG_MAX_PRED;
 
     constexpr int REC = mem_rec_len<MODEL, REAL>();
     REAL *lwg = reinterpret_cast<REAL *>(P.scratch);                // [N]
     // records start 16-byte aligned behind the log-weights
     REAL *cur = reinterpret_cast<REAL *>((reinterpret_cast<uintptr_t>(lwg + N) + 15) & ~(uintptr_t)15);   // [N][REC]
     REAL *nxt = cur + (size_t)REC * N;
+    // predictive: the statistic of the newest step, [lead k][particle]; folded into predv by the
+    // NEXT iteration's normalisation (its weights are log_normalize(new_logw), pf.py:72-76)
+    const bool predictive = (stat == PFG_STAT_PREDICTIVE);
+    const int KP = predictive ? P.num_steps_ahead + 1 : 0;
+    REAL *const pa = reinterpret_cast<REAL *>(P.pred_scratch);     // [KP][N]
+    int nact_prev = 0;                                              // leads with t+k < T at the last step
+    if (tid < PFG_MAX_PRED) predv[tid] = 0.0;
 
     Math<REAL, true> mth;
     mth.t.e2 = tabmem;
@@ -1262,6 +1274,15 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
         ml = wave_max(ml);
         if (lane == 0) red_maxf[wave] = ml;
+        const bool pred_upd = predictive && t > 0;      // fold step t-1's statistic (uniform)
+        if (pred_upd) {
+            for (int k = 0; k < nact_prev; ++k) {        // exact fp64 column maxima (np.max(add.T, axis=1))
+                double mk = -INFINITY;
+                for (int i = tid; i < N; i += NT) { const double a = (double)pa[(size_t)k * N + i]; mk = a > mk ? a : mk; }
+                mk = wave_max(mk);
+                if (lane == 0) red_pmax[k * NW + wave] = mk;
+            }
+        }
         __syncthreads();                                                        // barrier 1
         {
             float mm = red_maxf[0];
@@ -1269,9 +1290,19 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
             m = (double)mm;
         }
+        if (pred_upd) {
+            if (tid < nact_prev) {
+                double mk = red_pmax[tid * NW];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) { const double o = red_pmax[tid * NW + w]; mk = o > mk ? o : mk; }
+                pmaxv[tid] = mk;
+            }
+            __syncthreads();                                                    // barrier 1b
+        }
         // ---- (B,C) weights, per-chunk wave scans (unnormalised, wave-local) into the CDF -----
         const bool needS = needS_every || (t == T);
         {
+            double ptot = 0.0;
             double part[H];
 #pragma unroll
             for (int h = 0; h < H; ++h) part[h] = 0.0;
@@ -1285,9 +1316,21 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
 #pragma unroll
                     for (int h = 0; h < H; ++h) part[h] += (double)cur[(size_t)ii * REC + NS + h] * p;
                 }
+                if (pred_upd) {
+                    // sum over leads AND particles of w_i exp(add_ik - max_k): the reference's
+                    // np.sum has no axis (pf.py:74-76), so only the grand total is needed
+                    double e = 0.0;
+                    for (int k = 0; k < nact_prev; ++k)
+                        e += (double)mth.exp((REAL)((double)pa[(size_t)k * N + ii] - pmaxv[k]));
+                    ptot += p * e;
+                }
                 const double inc = wave_incl_scan(p);
                 if (v) cdf[cdf_phys(i)] = inc;
                 if (lane == WAVE - 1) red_scan[j * NW + wave] = inc;
+            }
+            if (pred_upd) {
+                ptot = wave_sum(ptot);
+                if (lane == 0) red_pt[wave] = ptot;
             }
             if (needS) {
 #pragma unroll
@@ -1338,6 +1381,15 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
 #pragma unroll
             for (int h = 0; h < H; ++h) filt[h] += S[h];
         }
+        if (pred_upd && tid < KP) {
+            // stats_k += max_k + log(sum): leads without a statistic (outside the window, or
+            // t+k >= T) have add = 0, i.e. max 0 and a unit contribution to the sum each
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red_pt[w];
+            tot = tot * invW + (double)(KP - nact_prev);
+            predv[tid] = (predv[tid] + (tid < nact_prev ? pmaxv[tid] : 0.0)) + log(tot);
+        }
         if (t == T) break;
 
         // ---- (D) normalise the CDF in place (own entries) -------------------------------------
@@ -1353,7 +1405,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         const double y_t = yv[t];
         const bool inside = (t >= t1) && (t < tL);
         const double wt = (inside && wv) ? wv[t - t1] : 1.0;
-        const bool use_stat = inside && (stat != PFG_STAT_NONE);
+        const bool use_stat = inside && (stat != PFG_STAT_NONE) && !predictive;
+        const int nact = (predictive && inside) ? (KP < T - t ? KP : T - t) : 0;
         // ---- (E..H) per particle: ancestor search, gather parent (HBM/L2), propose, publish ---
         auto sweep = [&](auto stat_tag) {
             constexpr int STAT = decltype(stat_tag)::value;
@@ -1393,6 +1446,41 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                     const REAL sm = (lam * sp[h] + oml * (REAL)S[h]) + av;      // pf.py:175-179 / :78-80
                     sp[h] = is_filter ? av : sm;
                 }
+                if (predictive && inside) {
+                    // [log Pr(y_{t+k} | x_{t+1})]_k of the new particle: svm/helper.py:352-395
+                    // (Ntilde = 1), lgssm/helper.py:1281-1336, garch/helper.py:374-412
+                    REAL xm = xn[0], s2 = (MODEL == PFG_MODEL_GARCH) ? xn[NS - 1] : (REAL)0;
+                    REAL cov = (REAL)0;
+                    const REAL Qv = (MODEL == PFG_MODEL_GARCH) ? (REAL)0 : (REAL)(1.0 / (double)c.Qinv);
+                    for (int k = 0; k < nact; ++k) {
+                        REAL zk = (REAL)0;
+                        if (MODEL != PFG_MODEL_LGSSM) {
+                            if (RNG == PFG_RNG_REPLAY) zk = (REAL)P.pred_z[((size_t)t * KP + k) * N + ii];
+                            else { REAL zb; mth.normal_pair(rng.next(), rng.next(), zk, zb); }
+                        }
+                        const REAL yk = (REAL)yv[t + k];
+                        REAL a;
+                        if (MODEL == PFG_MODEL_SVM) {
+                            const REAL ypc = c.R * mth.exp(xm + mth.sqrt(cov) * zk);
+                            a = ((REAL)-0.5 * (yk * yk) / ypc + c.c0) - (REAL)0.5 * mth.log(ypc);
+                            xm = c.A * xm;
+                            cov = Qv + c.A * c.A * cov;
+                        } else if (MODEL == PFG_MODEL_LGSSM) {
+                            const REAL diff = yk - xm * c.C;
+                            const REAL ypc = c.R + c.C * (cov * c.C);
+                            a = ((REAL)-0.5 * (diff * diff) / ypc + c.c0) - (REAL)0.5 * mth.log(ypc);
+                            xm = xm * c.A;
+                            cov = Qv + c.A * (cov * c.A);
+                        } else {
+                            const REAL diff = yk - xm;
+                            a = ((REAL)-0.5 * (diff * diff) / c.R + c.c0) - (REAL)0.5 * mth.log(c.R);
+                            const REAL s2n = c.alpha + c.beta * (xm * xm) + c.gamma * s2;   // prior_kernel.rv
+                            xm = mth.sqrt(s2n) * zk;
+                            s2 = s2n;
+                        }
+                        if (v) pa[(size_t)k * N + i] = a * (REAL)wt;
+                    }
+                }
                 if (v) {
                     lwg[i] = lwn;
 #pragma unroll
@@ -1418,6 +1506,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
         { REAL *tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
+        nact_prev = nact;
         // children (global stores) must be visible to next step's gathers: barrier 1 of the next
         // iteration orders them (__syncthreads = waitcnt + workgroup barrier, same CU / same L1)
     }
@@ -1437,6 +1526,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
 #pragma unroll
         for (int h = 0; h < H; ++h) P.out[h] = is_filter ? filt[h] : S[h];
         P.out[4] = ll; P.out[5] = W; P.out[6] = m; P.out[7] = tie;
+    }
+    if (predictive && P.pred_out) {
+        __syncthreads();
+        if (tid < PFG_MAX_PRED) P.pred_out[tid] = tid < KP ? predv[tid] : 0.0;
     }
     if (P.final_x) {
         for (int i = tid; i < N; i += NT) {

@@ -231,13 +231,15 @@ int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
 }
 
 int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
-             const pfg_dev_problem *dp, hipStream_t st, int smoother = PFG_SMOOTHER_NEMETH) {
+             const pfg_dev_problem *dp, hipStream_t st, int smoother = PFG_SMOOTHER_NEMETH,
+             bool force_mem = false) {
     int rc = check_combo(ctx, model, kernel, dtype, rng);
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
     int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis
             : smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC ? kVariantSystematic
+            : (force_mem && n_max <= pfg::MEM_MAX_N) ? kVariantMem
             : pick_variant(model, dtype, rng, n_max);
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
@@ -531,7 +533,19 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u))))
                 return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools");
         }
-        if (q.stat < PFG_STAT_SCORE || q.stat > PFG_STAT_NONE) return fail(ctx, PFG_ERR_INVALID, id + "bad stat id");
+        if (q.stat < PFG_STAT_SCORE || q.stat > PFG_STAT_PREDICTIVE) return fail(ctx, PFG_ERR_INVALID, id + "bad stat id");
+        if ((q.stat == PFG_STAT_PREDICTIVE) != (ps[0].stat == PFG_STAT_PREDICTIVE))
+            return fail(ctx, PFG_ERR_INVALID, id + "the predictive statistic cannot share a batch with others");
+        if (q.stat == PFG_STAT_PREDICTIVE) {
+            if (q.smoother != PFG_SMOOTHER_FILTER)                                  // svm/helper.py:209-210
+                return fail(ctx, PFG_ERR_INVALID, id + "Only can use pf = 'filter' since we are filtering");
+            if (q.num_steps_ahead < 0 || q.num_steps_ahead >= PFG_MAX_PRED)
+                return fail(ctx, PFG_ERR_INVALID, id + "num_steps_ahead must be in [0, 15]");
+            if (q.N > pfg::MEM_MAX_N)
+                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "N exceeds the supported maximum of 16384");
+            if (rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM && q.T > 0 && !q.pred_z)
+                return fail(ctx, PFG_ERR_INVALID, id + "REPLAY predictive needs the pred_z pool");
+        }
         if (!q.theta) return fail(ctx, PFG_ERR_INVALID, id + "theta is NULL");
         if (q.T > 0 && !q.y) return fail(ctx, PFG_ERR_INVALID, id + "observations are NULL");
         if (rng == PFG_RNG_REPLAY && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
@@ -556,8 +570,10 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (q.init_x) n_in += (size_t)q.N * (NS + 1) + (q.init_stats ? (size_t)q.N * H : 0);
         if (q.smoother == PFG_SMOOTHER_PARIS && rng == PFG_RNG_REPLAY)
             n_in += (size_t)q.T * q.Ntilde * q.N * (1 + 2 * (size_t)q.max_accept_reject);
+        if (q.stat == PFG_STAT_PREDICTIVE && rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM)
+            n_in += (size_t)q.T * (q.num_steps_ahead + 1) * q.N;
         const pfg_result &r = rs[b];
-        n_out += PFG_OUT_DOUBLES;
+        n_out += PFG_OUT_DOUBLES + (q.stat == PFG_STAT_PREDICTIVE ? PFG_MAX_PRED : 0);
         if (r.x_T) n_out += (size_t)q.N * NS;
         if (r.logw_T) n_out += q.N;
         if (r.stats_T) n_out += (size_t)q.N * H;
@@ -574,12 +590,15 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     }
     const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
     const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
-    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic : pick_variant(model, dtype, rng, n_max);
+    const bool predictive = ps[0].stat == PFG_STAT_PREDICTIVE;   // large-N kernel only (any N)
+    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic
+                        : predictive ? kVariantMem : pick_variant(model, dtype, rng, n_max);
     if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
     size_t n_scratch = 0;                  // bytes; every window of the batch gets n_max-sized state
-    const size_t scratch_each = (scratch_bytes(model, dtype, n_max) + 255) / 256 * 256;
+    const size_t pred_each = predictive ? ((size_t)n_max * PFG_MAX_PRED * (dtype == PFG_F64 ? 8 : 4) + 255) / 256 * 256 : 0;
+    const size_t scratch_each = (scratch_bytes(model, dtype, n_max) + 255) / 256 * 256 + pred_each;
     if (variant == kVariantMem) n_scratch = scratch_each * (size_t)B;
 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
@@ -645,6 +664,12 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                 d.paris_man_u = put(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
             }
         }
+        if (predictive) {
+            d.num_steps_ahead = q.num_steps_ahead;
+            if (rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM)
+                d.pred_z = put(q.pred_z, (size_t)q.T * (q.num_steps_ahead + 1) * q.N);
+            d.pred_out = take(true, PFG_MAX_PRED);
+        }
         d.out = take(true, PFG_OUT_DOUBLES);
         d.final_x = take(r.x_T != nullptr, (size_t)q.N * NS);
         d.final_logw = take(r.logw_T != nullptr, q.N);
@@ -657,6 +682,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.step_ctr = nullptr;
         d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
                               : nullptr;
+        if (predictive) d.pred_scratch = static_cast<char *>(d.scratch) + (scratch_each - pred_each);
         d.prior_mean = q.prior_mean; d.prior_var = q.prior_var; d.lambduh = q.lambduh;
         d.seed = q.seed; d.stream = q.stream;
         d.T = q.T; d.t1 = q.t1; d.tL = tL; d.N = q.N;
@@ -669,7 +695,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
     rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
-                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC : PFG_SMOOTHER_NEMETH);
+                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC : PFG_SMOOTHER_NEMETH,
+                  predictive);
     if (rc) return rc;
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -683,6 +710,10 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         const double *o = host_of(d.out);
         for (int h = 0; h < PFG_MAX_STAT; ++h) r.mean_stat[h] = o[h];
         r.loglik = o[4];
+        if (predictive) {
+            const double *pp = host_of(d.pred_out);
+            for (int k = 0; k < PFG_MAX_PRED; ++k) r.pred[k] = pp[k];
+        }
         auto fetch = [&](double *dst, const double *dev, size_t n) {
             if (dst && dev) std::memcpy(dst, host_of(dev), n * 8);
         };

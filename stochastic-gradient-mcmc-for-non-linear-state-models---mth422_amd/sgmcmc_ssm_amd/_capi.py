@@ -13,11 +13,11 @@ from . import _build
 MODEL = {"svm": 0, "garch": 1, "lgssm": 2}
 KERNEL = {"prior": 0, "optimal": 1}
 SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2, "nemeth_systematic": 3}
-STAT = {"score": 0, "suff": 1, "none": 2}
+STAT = {"score": 0, "suff": 1, "none": 2, "predictive": 3}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
-MAX_STAT, MAX_THETA, OUT_DOUBLES = 4, 4, 8
+MAX_STAT, MAX_THETA, OUT_DOUBLES, MAX_PRED = 4, 4, 8, 16
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
 THETA_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
@@ -40,6 +40,8 @@ class Problem(C.Structure):
         ("init_x", _dp), ("init_logw", _dp), ("init_stats", _dp),
         ("Ntilde", C.c_int32), ("max_accept_reject", C.c_int32),
         ("paris_idx_u", _dp), ("paris_acc_u", _dp), ("paris_man_u", _dp),
+        ("num_steps_ahead", C.c_int32), ("reserved2", C.c_int32),
+        ("pred_z", _dp),
     ]
 
 
@@ -50,6 +52,7 @@ class Result(C.Structure):
         ("trace_x", _dp), ("trace_logw", _dp), ("trace_stats", _dp), ("trace_ll", _dp),
         ("status", C.c_int32), ("reserved", C.c_int32),
         ("trace_anc", C.POINTER(C.c_int32)),
+        ("pred", C.c_double * MAX_PRED),
     ]
 
 
@@ -77,6 +80,8 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("paris_idx_u", "u8"), ("paris_acc_u", "u8"), ("paris_man_u", "u8"),
     ("Ntilde", "i4"), ("max_accept_reject", "i4"),
     ("trace_anc", "u8"),
+    ("pred_z", "u8"), ("pred_out", "u8"), ("pred_scratch", "u8"),
+    ("num_steps_ahead", "i4"), ("reserved3", "i4"),
 ], align=True)
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
@@ -241,8 +246,9 @@ class Context:
             arrs = dict(y=y, theta=theta)
             p.Ntilde = int(q.get("Ntilde", 2))
             p.max_accept_reject = int(q.get("max_accept_reject", 0))
+            p.num_steps_ahead = int(q.get("num_steps_ahead", 0))
             for name in ("weights", "z0", "u", "z", "init_x", "init_logw", "init_stats",
-                         "paris_idx_u", "paris_acc_u", "paris_man_u"):
+                         "paris_idx_u", "paris_acc_u", "paris_man_u", "pred_z"):
                 v = q.get(name, None)
                 arrs[name] = None if v is None else _as_f64(v).reshape(-1)
             if arrs["weights"] is not None and arrs["weights"].shape[0] < p.tL - p.t1:
@@ -264,6 +270,10 @@ class Context:
                 for name, need in (("paris_idx_u", pool), ("paris_acc_u", pool), ("paris_man_u", T * p.Ntilde * N)):
                     if need and (arrs[name] is None or arrs[name].shape[0] != need):
                         raise ValueError("{0} must have {1} entries".format(name, need))
+            if p.stat == STAT["predictive"] and p.rng == RNG["replay"] and model != "lgssm":
+                need = T * (p.num_steps_ahead + 1) * N
+                if need and (arrs["pred_z"] is None or arrs["pred_z"].shape[0] != need):
+                    raise ValueError("pred_z must have T*(num_steps_ahead+1)*N = {0} entries".format(need))
             is_filter = p.smoother == SMOOTHER["filter"]
             if want_final or want_trace:
                 o["x_t"] = np.zeros((N, ns))
@@ -290,6 +300,8 @@ class Context:
             h = 3 if problems[b].get("stat", "score") != "score" else STAT_DIM[problems[b]["model"]]
             o["mean_stat"] = np.array(rs[b].mean_stat[:h])
             o["loglik"] = float(rs[b].loglik)
+            if problems[b].get("stat", "score") == "predictive":
+                o["predictive"] = np.array(rs[b].pred[:int(problems[b].get("num_steps_ahead", 0)) + 1])
             for name in ("statistics", "all_statistics"):
                 if name in o:
                     o[name] = o[name][..., :h]

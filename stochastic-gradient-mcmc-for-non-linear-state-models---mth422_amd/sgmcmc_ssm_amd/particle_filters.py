@@ -78,6 +78,25 @@ def draw_replay_streams(N, T, random_state=None, buffers=None):
     return z0, u, z
 
 
+def draw_replay_streams_predictive(model, N, T, t1, tL, num_steps_ahead, random_state=None):
+    """The legacy-stream consumption of one pf_predictive_loglikelihood_estimate run: as
+    draw_replay_streams, plus -- inside the window, after the step's N normals -- N normals per lead
+    k with t + k < T (svm/helper.py:380 `np.random.normal` inside svm_predictive_loglikelihood;
+    garch/helper.py:405 prior_kernel.rv; LGSSM draws none).  Returns z0, u, z, pred_z [T][K+1][N]."""
+    rs = np.random if random_state is None else random_state
+    K1 = num_steps_ahead + 1
+    z0 = rs.normal(size=N)
+    u, z = np.empty((T, N)), np.empty((T, N))
+    pred_z = None if model == "lgssm" else np.zeros((T, K1, N))
+    for t in range(T):
+        u[t] = rs.random_sample(N)
+        z[t] = rs.normal(size=N)
+        if pred_z is not None and t1 <= t < tL:
+            for k in range(min(K1, T - t)):
+                pred_z[t, k] = rs.normal(size=N)
+    return z0, u, z, pred_z
+
+
 _device_rng_calls = [0]
 
 
@@ -134,7 +153,14 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
              prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
              prior_var=float(np.asarray(prior_var).reshape(-1)[0]),
              y=y, weights=weights, theta=theta, flags=flags)
-    if rng == "replay":
+    if stat == "predictive":
+        if smoother != "filter":
+            raise ValueError("Only can use pf = 'filter' since we are filtering")
+        q["num_steps_ahead"] = int(kwargs.pop("num_steps_ahead", 5))
+    if rng == "replay" and stat == "predictive":
+        q["z0"], q["u"], q["z"], q["pred_z"] = draw_replay_streams_predictive(
+            model, int(N), T, q["t1"], min(q["tL"], T), q["num_steps_ahead"], random_state)
+    elif rng == "replay":
         bufs = _stream_buffers(int(N), T)
         q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state, buffers=bufs)
         q["_stream_bufs"] = bufs
@@ -169,7 +195,9 @@ def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
 
 def _to_reference_dict(o, q):
     out = dict(loglikelihood_estimate=o["loglik"])
-    if q["smoother"] == "filter":
+    if "predictive" in o:
+        out["statistics"] = o["predictive"]
+    elif q["smoother"] == "filter":
         out["statistics"] = o["mean_stat"]
     else:
         out["mean_statistic"] = o["mean_stat"]

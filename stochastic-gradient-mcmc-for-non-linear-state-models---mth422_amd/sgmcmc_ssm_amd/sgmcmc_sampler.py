@@ -148,6 +148,23 @@ class PFHelper(object):
                             pf, N, kernel, forward_message, stat="suff", **kwargs)
         return _pf.run_windows([q])[0]["loglikelihood_estimate"]
 
+    def pf_predictive_loglikelihood_estimate(self, observations, parameters, num_steps_ahead=5,
+                                             subsequence_start=0, subsequence_end=None, pf="filter",
+                                             N=1000, kernel=None, forward_message=None, **kwargs):
+        """Particle-filter predictive log-likelihoods for leads k = 0..num_steps_ahead
+        (svm/helper.py:187-247, garch/helper.py:172-231, lgssm/helper.py:1048-1087): the filter with
+        the k-step-ahead statistic folded in by the reference's logsumexp update (pf.py:72-76,
+        including its axis-less sum); entry 0 is replaced by the log-likelihood estimate."""
+        if pf != "filter":
+            raise ValueError("Only can use pf = 'filter' since we are filtering")
+        q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, None,
+                            pf, N, kernel, forward_message, stat="predictive",
+                            num_steps_ahead=num_steps_ahead, **kwargs)
+        out = _pf.run_windows([q])[0]
+        pred = np.array(out["statistics"], dtype=float)
+        pred[0] = out["loglikelihood_estimate"]
+        return pred
+
 
     def pf_latent_var_distr(self, observations, parameters, lag=None, subsequence_start=0,
                             subsequence_end=None, weights=None, pf="poyiadjis_N", N=1000, kernel=None,
@@ -274,6 +291,33 @@ class SGMCMCSampler(object):
                                                       subsequence_length=subsequence_length, T=T)
             probs.append((self._window_problem(bd, observations, "suff", **kwargs), minibatch_size))
         return probs
+
+    def predictive_loglikelihood(self, kind='pf', num_steps_ahead=10, subsequence_length=-1,
+                                 minibatch_size=1, buffer_length=10, num_samples=1000,
+                                 parameters=None, observations=None, **kwargs):
+        """Predictive log-likelihoods [sum_t log Pr(y_{t+k} | y_{<=t})]_{k=0..num_steps_ahead}
+        by particle filter (sgmcmc_sampler.py:50-128, kind='pf' branch; as there, the filter runs at
+        self.parameters whatever `parameters` is)."""
+        self._require_pf(kind)
+        observations = self._get_observations(observations, check_shape=kwargs.pop('check_shape', True))
+        T = observations.shape[0]
+        if kwargs.get("N", None) is None:
+            kwargs['N'] = num_samples
+        pred_loglikelihood = np.zeros(num_steps_ahead + 1)
+        for _ in range(minibatch_size):
+            out = self._random_subsequence_and_buffers(buffer_length=buffer_length,
+                                                      subsequence_length=subsequence_length, T=T)
+            relative_start = out['subsequence_start'] - out['left_buffer_start']
+            relative_end = out['subsequence_end'] - out['left_buffer_start']
+            buffer_ = observations[out['left_buffer_start']:out['right_buffer_end']]
+            add = self.message_helper.pf_predictive_loglikelihood_estimate(
+                observations=buffer_, parameters=self.parameters, num_steps_ahead=num_steps_ahead,
+                subsequence_start=relative_start, subsequence_end=relative_end, **kwargs)
+            for ll in range(num_steps_ahead + 1):
+                pred_loglikelihood[ll] += add[ll] * (T - ll) / (
+                    out['subsequence_end'] - out['subsequence_start'] - ll)
+        pred_loglikelihood *= 1.0 / minibatch_size
+        return pred_loglikelihood
 
     def noisy_loglikelihood(self, **kwargs):
         """Subsequence approximation to the log-likelihood (kind='pf')."""
@@ -661,6 +705,18 @@ class SeqSGMCMCSampler(object):
             raise ValueError("NaNs in loglikelihood")
         if num_sequences != -1:
             value *= self._get_T(**kwargs) / S
+        return value
+
+    def predictive_loglikelihood(self, num_sequences=-1, observations=None, tqdm=None, **kwargs):
+        """Sum of the per-sequence predictive log-likelihoods (sgmcmc_sampler.py:1224-1247)."""
+        observations = self._get_observations(observations)
+        value, S = 0, 0.0
+        for index in self._choose_sequences(observations, num_sequences):
+            S += observations[index].shape[0]
+            value = value + SGMCMCSampler.predictive_loglikelihood(
+                self, observations=observations[index], check_shape=False, **kwargs)
+        if num_sequences != -1:
+            value = value * (self._get_T(**kwargs) / S)
         return value
 
     def _grad_groups(self, num_sequences=-1, **kwargs):

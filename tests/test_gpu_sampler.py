@@ -5,7 +5,8 @@ parallel-sum order only; the bar in BASELINE.json is gradient L2 error < 1e-4)."
 import numpy as np
 import pytest
 
-from test_host_logic import (_check_sampler_case, _check_seq_and_minibatch, default_params, vec)
+from test_host_logic import (_check_predictive, _check_sampler_case, _check_seq_and_minibatch, default_params,
+                             vec)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-8
@@ -19,6 +20,30 @@ def test_sampler_trajectories_match_reference_gpu(golden_sampler):
 @pytest.mark.parametrize("model", ["svm", "garch", "lgssm"])
 def test_seq_sampler_and_minibatch_gpu(golden_sampler, model):
     _check_seq_and_minibatch(golden_sampler, model, exact=False, rtol=RTOL)
+
+
+@pytest.mark.parametrize("model", ["svm", "garch", "lgssm"])
+def test_predictive_loglikelihood_gpu(model):
+    """pf_predictive_loglikelihood_estimate / predictive_loglikelihood(kind='pf') on the device
+    (large-N kernel's predictive mode) vs the reference fixtures, fp64 REPLAY."""
+    _check_predictive(model, exact=False, rtol=RTOL)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_predictive_device_rng_gpu(dtype):
+    """Device-RNG predictive run: same estimator, different random numbers -- agrees with the
+    replayed run within Monte-Carlo error (N = 4000 particles; also covers N > 1024)."""
+    from sgmcmc_ssm_amd.models.svm import SVMSampler, generate_svm_data
+    np.random.seed(8)
+    p = default_params("svm")
+    y = generate_svm_data(T=60, parameters=p)["observations"]
+    sampler = SVMSampler(n=1, m=1, observations=y, parameters=p)
+    np.random.seed(1)
+    ref = sampler.predictive_loglikelihood(kind="pf", num_steps_ahead=3, N=4000)
+    np.random.seed(2)
+    got = sampler.predictive_loglikelihood(kind="pf", num_steps_ahead=3, N=4000, rng="device", dtype=dtype)
+    assert got.shape == (4,) and np.all(np.isfinite(got))
+    np.testing.assert_allclose(got, ref, atol=1.5, rtol=0.02)
 
 
 def test_helper_known_answer_gpu(golden_window):
