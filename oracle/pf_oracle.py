@@ -421,10 +421,13 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
     elif pf == "paris":
         if paris_draws is None:
             raise ValueError("pf='paris' needs paris_draws (NpDraws or PoolDraws)")
+    elif pf == "poyiadjis_N2":
+        pass
     elif pf != "filter":
         raise ValueError("Unrecognized pf = {0}".format(pf))
     is_filter = (pf == "filter")
     is_paris = (pf == "paris")
+    is_n2 = (pf == "poyiadjis_N2")
     d = derived(model, theta)
     if model == "svm" and abs(d["A"]) > 1:
         raise ValueError("Current AR parameter is |A| = {0} > 1".format(abs(d["A"])))
@@ -454,7 +457,7 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         if inside and weights is not None:
             weight_t = float(weights[t - t1])
 
-        if not is_filter and not is_paris:
+        if not is_filter and not is_paris and not is_n2:
             # nemeth_smoother: S from the *previous* weights (pf.py:161)
             S = np.sum(stats.T * log_normalize(logw), axis=1)
         # pf(): resample every step, propose, weight (pf.py:26-38)
@@ -465,6 +468,29 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
         x_next = kernel_rv(model, kernel, d, parents, y[t], z[t])
         new_logw = kernel_reweight(model, kernel, d, parents, x_next, y[t])
 
+        if is_n2:
+            # poyiadjis_smoother (pf.py:84-136): every child averages over ALL parents with the
+            # backward weights  w_j q(child | x_j)  (normalised per child)
+            bw = np.zeros((N, N))
+            for i in range(N):
+                child_ll = prior_log_density(model, d, x, np.outer(np.ones(N), x_next[i]))
+                bw[i] = log_normalize(logw + child_ll)
+            idx = np.array([ii for _ in range(N) for ii in range(N)])
+            new_idx = np.array([ii for ii in range(N) for _ in range(N)])
+            if inside and stat == "score":
+                add = score_statistic(model, d, x[idx], x_next[new_idx], y[t])
+            elif inside and stat == "suff":
+                add = sufficient_statistic(model, x[idx], x_next[new_idx])
+            else:
+                add = np.zeros((N * N, h))
+            add = add * weight_t
+            stats = np.einsum('ijk,ij->ik', np.reshape(stats[idx] + add, (N, N, -1)), bw)
+            x, logw = x_next, new_logw
+            if inside:
+                loglik += weight_t * np.log(np.mean(np.exp(logw)))
+            if save_all:
+                all_x.append(x); all_lw.append(logw); all_s.append(stats); all_ll.append(loglik)
+            continue
         if is_paris:
             # paris_smoother (pf.py:183-258): rewire Ntilde backward-sampled parents per child
             J = paris_backward_indices(model, d, x, logw, x_next, Ntilde, paris_draws, t,

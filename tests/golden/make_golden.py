@@ -507,6 +507,49 @@ def make_predictive_fixtures():
     np.savez_compressed(os.path.join(HERE, "predictive.npz"), **out)
 
 
+def make_n2_fixtures():
+    """poyiadjis_smoother, the O(N^2) algorithm (pf.py:84-136): traced tiny cases for every
+    (model, kernel), and window-level cases at sizes the N^2 NumPy arrays still allow."""
+    out, meta = {}, []
+    combos = [("svm", "prior"), ("garch", "prior"), ("garch", "optimal"),
+              ("lgssm", "prior"), ("lgssm", "optimal")]
+    cases = []
+    for ci, (model, kernel) in enumerate(combos):
+        cases.append((model, kernel, "score", 24, 10, 2, 8, True, True, 3000 + ci))
+        cases.append((model, kernel, "suff", 24, 10, 2, 8, True, True, 3100 + ci))
+    cases += [("svm", "prior", "score", 300, 12, 3, 10, True, False, 3200),     # N > 256: 4 particles per thread
+              ("garch", "optimal", "score", 130, 9, 0, 9, False, False, 3201),   # ragged N
+              ("lgssm", "optimal", "score", 257, 6, 1, 6, False, False, 3202)]
+    for model, kernel, stat, N, T, t1, tL, use_w, save_all, seed in cases:
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(seed + 50000)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        pm, pv = prior_x(model, p, data)
+        weights = (1.0 + 0.5 * np.arange(tL - t1)) if use_w else None
+        res = run_window(model, kernel, "poyiadjis_N2", stat, p, y, N, t1, tL, weights, pm, pv, seed,
+                         save_all=save_all)
+        key = "n{0}".format(len(meta))
+        meta.append(dict(key=key, model=model, kernel=kernel, pf="poyiadjis_N2", stat=stat, lambduh=None,
+                         N=N, T=T, t1=t1, tL=tL, seed=seed, prior_mean=pm, prior_var=pv,
+                         has_weights=bool(use_w), traced=bool(save_all)))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        if weights is not None:
+            out[key + "/weights"] = weights
+        out[key + "/mean_statistic"] = np.asarray(res["mean_statistic"], dtype=float)
+        out[key + "/loglikelihood_estimate"] = np.float64(res["loglikelihood_estimate"])
+        out[key + "/x_t"] = np.asarray(res["x_t"], dtype=float)
+        out[key + "/log_weights"] = np.asarray(res["log_weights"], dtype=float)
+        out[key + "/statistics"] = np.asarray(res["statistics"], dtype=float)
+        if save_all:
+            for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+                out[key + "/" + name] = np.asarray(res[name], dtype=float)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "n2.npz"), **out)
+
+
 def make_ksd_fixtures():
     """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
     from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
@@ -534,6 +577,8 @@ if __name__ == "__main__":
         make_sampler_fixtures()
     if only in ("", "ksd"):
         make_ksd_fixtures()
+    if only in ("", "n2"):
+        make_n2_fixtures()
     if only in ("", "paris"):
         make_paris_fixtures()
     if only in ("", "latent"):

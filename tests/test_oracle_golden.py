@@ -127,3 +127,20 @@ def test_predictive_oracle_bit_exact():
             m["model"], g.get(m["key"], "theta"), g.get(m["key"], "y"), m["N"], rng=rng, num_steps_ahead=m["K"],
             kernel=kernel, t1=m["t1"], tL=m["tL"], prior_mean=m["prior_mean"], prior_var=m["prior_var"])
         assert np.array_equal(pred, g.get(m["key"], "pred")), (m, pred, g.get(m["key"], "pred"))
+
+
+def test_poyiadjis_n2_oracle_bit_exact():
+    """The O(N^2) Poyiadjis smoother (pf.py:84-136) restatement vs the reference: traced tiny
+    cases for every (model, kernel) and statistic, window-level cases up to N = 300."""
+    from conftest import Golden
+    g = Golden("n2.npz")
+    assert len(g.meta) == 13
+    for meta in g.meta:
+        out = _run(meta, g, save_all=meta["traced"])
+        key = meta["key"]
+        assert out["loglikelihood_estimate"] == float(g.get(key, "loglikelihood_estimate")), meta
+        for name in ("x_t", "log_weights", "statistics", "mean_statistic"):
+            assert np.array_equal(np.asarray(out[name], dtype=float), g.get(key, name)), (meta, name)
+        if meta["traced"]:
+            for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+                assert np.array_equal(np.asarray(out[name], dtype=float), g.get(key, name)), (meta, name)
