@@ -56,7 +56,11 @@ enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTH
                      * pf.py:26-30): NEMETH with systematic resampling, u_i = (i + u0)/N with ONE
                      * uniform u0 per timestep.  DEVICE rng, N <= 1024; parity-unpinned, checked
                      * statistically.  Its own kernel instantiation (keeps the hot path untouched). */
-                    PFG_SMOOTHER_NEMETH_SYSTEMATIC = 3 };
+                    PFG_SMOOTHER_NEMETH_SYSTEMATIC = 3,
+                    /* poyiadjis_smoother, the O(N^2) algorithm (pf.py:84-136): every child averages
+                     * stats_j + w_t h(x_j, child) over ALL parents j with the backward weights
+                     * w_j q(child | x_j), normalised per child.  N <= 1024. */
+                    PFG_SMOOTHER_POYIADJIS_N2 = 4 };
 /* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
 enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2,
                 /* k-step-ahead predictive log-likelihoods accumulated with the filter's
@@ -181,7 +185,7 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 /* as pfg_launch_device for a batch whose descriptors all have smoother = `smoother`
- * (PFG_SMOOTHER_PARIS and PFG_SMOOTHER_NEMETH_SYSTEMATIC have their own kernel instantiations;
+ * (PFG_SMOOTHER_PARIS, _NEMETH_SYSTEMATIC and _POYIADJIS_N2 have their own kernel instantiations;
  * the plain entry point serves NEMETH / FILTER) */
 int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
                                int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);

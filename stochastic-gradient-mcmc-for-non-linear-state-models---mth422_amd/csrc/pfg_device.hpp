@@ -19,7 +19,7 @@ namespace pfg {
 
 constexpr int WAVE = 64;
 // kernel instantiation modes beyond the plain filter / Nemeth path
-constexpr int MODE_PLAIN = 0, MODE_PARIS = 1, MODE_SYSTEMATIC = 2;
+constexpr int MODE_PLAIN = 0, MODE_PARIS = 1, MODE_SYSTEMATIC = 2, MODE_N2 = 3;
 constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
 
 // ------------------------------------------------------------------------------------
@@ -498,7 +498,7 @@ template <int NT, int PPT> struct RegLayout {
 // the fp64 math runs on LDS tables; the single-buffer variant spends its LDS on particles.
 template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
-    constexpr bool PARIS = (MODE == MODE_PARIS);
+    constexpr bool PARIS = (MODE == MODE_PARIS || MODE == MODE_N2);   // parents' log-weights in LDS
     size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
     constexpr bool FAST = fast_layout(NT, PP);
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
@@ -521,7 +521,8 @@ template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool P
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr bool PARIS = (MODE == MODE_PARIS);
     constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
-    static_assert(!PARIS || PP, "PaRIS needs the parents intact while children are built: ping-pong buffers");
+    constexpr bool N2 = (MODE == MODE_N2);
+    static_assert(!(PARIS || N2) || PP, "PaRIS / O(N^2) need the parents intact while children are built: ping-pong buffers");
     static_assert(!systematic || RNG == PFG_RNG_DEVICE, "systematic resampling draws its offset on the device");
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
     const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : (P.smoother == PFG_SMOOTHER_PARIS ? 1.0 : P.lambduh);
+    const double lam_d = is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const double *__restrict__ const yv = P.y;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         for (int k = 0; k < PPT; ++k)
             if (valid[k]) {
                 cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
-                if (PARIS) lwL[k * NT + tid] = lw[k];
+                if (PARIS || N2) lwL[k * NT + tid] = lw[k];
             }
         __syncthreads();                                                        // barrier 3
 
@@ -1032,8 +1033,85 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 }
             }
         };
+        // Poyiadjis O(N^2) (pf.py:84-136): children are proposed from the filter's ancestors, then
+        // every child averages  stats_j + w_t h(x_j, child)  over ALL parents j with the backward
+        // weights  log_normalize(logw_j + log q(child | x_j)).  Every lane walks the parents in the
+        // same order (LDS broadcast reads); two passes: exact per-child maximum, then exp-sums.
+        auto n2_slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+            REAL xn[PPT][NS], lwn[PPT], aux[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                REAL xp[NS], add[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
+                aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
+                if (valid[k]) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                }
+            }
+            REAL mx[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) mx[k] = (REAL)(-INFINITY);
+#pragma unroll 2
+            for (int j = 0; j < N; ++j) {
+                REAL xj[NS];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+                const REAL lj = lwL[j];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const REAL v = lj + backward_log_ratio<MODEL, REAL>(c, mth, xj, xn[k]);
+                    mx[k] = v > mx[k] ? v : mx[k];
+                }
+            }
+            REAL den[PPT], num[PPT][H];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                den[k] = (REAL)0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) num[k][h] = (REAL)0;
+            }
+#pragma unroll 2
+            for (int j = 0; j < N; ++j) {
+                REAL xj[NS], sj[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sj[h] = cur[(size_t)(NS + h) * NL + j];
+                const REAL lj = lwL[j];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const REAL e = mth.exp((lj + backward_log_ratio<MODEL, REAL>(c, mth, xj, xn[k])) - mx[k]);
+                    REAL aj[H];
+                    additive_stat<MODEL, STAT, REAL>(c, xj, xn[k], (REAL)y_t, aux[k], aj);
+                    den[k] += e;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                        num[k][h] += e * (sj[h] + a);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
+                if (valid[k]) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = num[k][h] / den[k];
+                }
+            }
+        };
         bool did_paris = false;
-        if constexpr (PARIS) {
+        if constexpr (N2) {
+            if (stat == PFG_STAT_SCORE) n2_slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else n2_slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+            did_paris = true;
+        }
+        if constexpr (MODE == MODE_PARIS) {
             if (P.smoother == PFG_SMOOTHER_PARIS) {
                 if (stat == PFG_STAT_SCORE) paris_slots(std::integral_constant<int, PFG_STAT_SCORE>{});
                 else paris_slots(std::integral_constant<int, PFG_STAT_SUFF>{});

@@ -155,7 +155,30 @@ int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
     return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
 }
 
-constexpr int kVariantParis = -3, kVariantSystematic = -4;
+constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5;
+
+// O(N^2) Poyiadjis smoother instantiations (ping-pong variants, parents' log-weights in LDS)
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+int launch_n2_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>(n_max);
+    if (lds > kLdsLimit)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_n2(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 256) return launch_n2_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
+    if (n_max <= 1024) return launch_n2_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
+}
 
 // systematic-resampling instantiation (extension): device RNG, the fp64 / f32 default 256x4 variants
 template <int MODEL, int KERNEL, typename REAL, bool PP>
@@ -194,6 +217,14 @@ int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const p
         if (rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
         if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
         return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
+    }
+    if (v == kVariantN2) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_n2<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_n2<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
     }
     if (v == kVariantParis) {
         if (dtype == PFG_F64) {
@@ -239,6 +270,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
     int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis
             : smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC ? kVariantSystematic
+            : smoother == PFG_SMOOTHER_POYIADJIS_N2 ? kVariantN2
             : (force_mem && n_max <= pfg::MEM_MAX_N) ? kVariantMem
             : pick_variant(model, dtype, rng, n_max);
     if (v == -1)
@@ -440,7 +472,7 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
                                int B, const pfg_dev_problem *dev_probs, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_smoother: dev_probs is NULL");
-    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_NEMETH_SYSTEMATIC)
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N2)
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother);
@@ -523,8 +555,14 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (q.N < 1) return fail(ctx, PFG_ERR_INVALID, id + "N must be >= 1");
         if (q.T < 0) return fail(ctx, PFG_ERR_INVALID, id + "T must be >= 0");
         if (q.t1 < 0 || q.tL < q.t1) return fail(ctx, PFG_ERR_INVALID, id + "need 0 <= t1 <= tL");
-        if (q.smoother < PFG_SMOOTHER_NEMETH || q.smoother > PFG_SMOOTHER_NEMETH_SYSTEMATIC)
+        if (q.smoother < PFG_SMOOTHER_NEMETH || q.smoother > PFG_SMOOTHER_POYIADJIS_N2)
             return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
+        if ((q.smoother == PFG_SMOOTHER_POYIADJIS_N2) != (ps[0].smoother == PFG_SMOOTHER_POYIADJIS_N2))
+            return fail(ctx, PFG_ERR_INVALID, id + "pf = 'poyiadjis_N2' cannot share a batch with other smoothers");
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.N > 1024)
+            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'poyiadjis_N2' is implemented for N <= 1024");
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.stat == PFG_STAT_PREDICTIVE)
+            return fail(ctx, PFG_ERR_INVALID, id + "Only can use pf = 'filter' since we are filtering");
         if ((q.smoother == PFG_SMOOTHER_PARIS) != (ps[0].smoother == PFG_SMOOTHER_PARIS))
             return fail(ctx, PFG_ERR_INVALID, id + "pf = 'paris' cannot share a batch with other smoothers");
         if (q.smoother == PFG_SMOOTHER_PARIS) {
@@ -591,7 +629,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
     const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
     const bool predictive = ps[0].stat == PFG_STAT_PREDICTIVE;   // large-N kernel only (any N)
-    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic
+    const bool n2 = ps[0].smoother == PFG_SMOOTHER_POYIADJIS_N2;
+    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic : n2 ? kVariantN2
                         : predictive ? kVariantMem : pick_variant(model, dtype, rng, n_max);
     if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
@@ -695,7 +734,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
     rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
-                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC : PFG_SMOOTHER_NEMETH,
+                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC
+                               : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
                   predictive);
     if (rc) return rc;
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));

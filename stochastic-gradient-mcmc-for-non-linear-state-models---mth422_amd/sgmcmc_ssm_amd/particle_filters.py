@@ -20,8 +20,7 @@ import numpy as np
 
 from . import _capi
 
-PF_NAMES = ("nemeth", "poyiadjis_N", "filter", "paris")
-NOT_ON_DEVICE = ("poyiadjis_N2",)              # SURVEY.md 8(f) "next" row
+PF_NAMES = ("nemeth", "poyiadjis_N", "poyiadjis_N2", "filter", "paris")
 
 
 def _smoother_of(pf, kwargs):
@@ -37,9 +36,9 @@ def _smoother_of(pf, kwargs):
     if pf == "paris":
         kwargs.pop("lambduh", None)
         return "paris", 1.0
-    if pf in NOT_ON_DEVICE:
-        raise NotImplementedError(
-            "pf = '{0}' is not implemented on the HIP backend yet (O(N^2) smoother)".format(pf))
+    if pf == "poyiadjis_N2":
+        kwargs.pop("lambduh", None)
+        return "poyiadjis_n2", 1.0
     raise ValueError("Unrecognized pf = {0}".format(pf))
 
 

@@ -12,7 +12,7 @@ def run_windows_oracle(problems, ctx=None, want_final=False):
     for q in problems:
         if q["rng"] != "replay":
             raise ValueError("the oracle can only replay host streams")
-        pf = "filter" if q["smoother"] == "filter" else "nemeth"
+        pf = {"filter": "filter", "poyiadjis_n2": "poyiadjis_N2"}.get(q["smoother"], "nemeth")
         if q["stat"] == "predictive":
             pz = q.get("pred_z")
             r = po.pf_window(q["model"], q["theta"], q["y"], q["N"], q["z0"], q["u"], q["z"],

@@ -1,0 +1,108 @@
+"""GPU parity of the O(N^2) Poyiadjis smoother (PFG_SMOOTHER_POYIADJIS_N2, pf.py:84-136) against
+the reference fixtures (tests/golden/n2.npz) and, at N = 1000, against the CPU oracle's
+backward-weight algebra on one step.  fp64 REPLAY: the per-child softmax over parents is summed
+in index order on the device and pairwise / einsum-blocked in NumPy, exp/log differ in the last
+ulp -> rtol 1e-9 (statistics atol 1e-8), five orders inside the north-star bar (1e-4)."""
+import numpy as np
+import pytest
+
+from conftest import Golden
+from oracle import pf_oracle as po
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-9, 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sgmcmc_ssm_amd import _capi
+    return _capi.default_context(0)
+
+
+def _problem(m, g, dtype="f64", rng="replay"):
+    key = m["key"]
+    streams = po.draw_streams(np.random.RandomState(m["seed"]), m["N"], m["T"])
+    return dict(model=m["model"], kernel=m["kernel"], smoother="poyiadjis_n2", stat=m["stat"], dtype=dtype,
+                rng=rng, N=m["N"], t1=m["t1"], tL=m["tL"], lambduh=1.0, prior_mean=m["prior_mean"],
+                prior_var=m["prior_var"], y=g.get(key, "y"), weights=g.get(key, "weights"),
+                theta=g.get(key, "theta"), z0=streams[0], u=streams[1], z=streams[2], seed=11, stream=3)
+
+
+def test_n2_reference_fixtures_f64(ctx):
+    g = Golden("n2.npz")
+    for m in g.meta:
+        o = ctx.run_batch([_problem(m, g)], want_trace=True)[0]
+        key = m["key"]
+        ll = float(g.get(key, "loglikelihood_estimate"))
+        assert abs(o["loglik"] - ll) <= ATOL + RTOL * abs(ll), (m, o["loglik"], ll)
+        np.testing.assert_allclose(o["x_t"], g.get(key, "x_t"), rtol=RTOL, atol=ATOL, err_msg=str(m))
+        np.testing.assert_allclose(o["log_weights"], g.get(key, "log_weights"), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(o["statistics"], g.get(key, "statistics"), rtol=RTOL, atol=1e-8, err_msg=str(m))
+        ref = g.get(key, "mean_statistic")
+        assert np.linalg.norm(o["mean_stat"] - ref) <= 1e-8 * max(1.0, np.linalg.norm(ref)), (m, o["mean_stat"], ref)
+        if m["traced"]:
+            np.testing.assert_allclose(o["all_x_t"], g.get(key, "all_x_t"), rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(o["all_statistics"], g.get(key, "all_statistics"), rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(o["all_loglikelihood_estimate"], g.get(key, "all_loglikelihood_estimate"),
+                                       rtol=RTOL, atol=ATOL)
+
+
+def test_n2_batch_and_n1000_vs_oracle(ctx):
+    """N = 1000 (the BASELINE particle count), T = 3, a batch of three windows in one launch,
+    against the oracle on the same streams."""
+    rs = np.random.RandomState(5)
+    theta = np.array([0.95, 0.5 ** -0.5, 0.5 ** -0.5])
+    N, T = 1000, 3
+    probs, refs = [], []
+    for b in range(3):
+        y = rs.normal(size=T) * 1.5
+        z0, u, z = po.draw_streams(rs, N, T)
+        w = np.array([1.0, 2.0])
+        refs.append(po.pf_window("svm", theta, y, N, z0, u, z, kernel="prior", pf="poyiadjis_N2", stat="score",
+                                 t1=1, tL=3, weights=w, prior_mean=0.0, prior_var=2.0))
+        probs.append(dict(model="svm", kernel="prior", smoother="poyiadjis_n2", stat="score", dtype="f64",
+                          rng="replay", N=N, t1=1, tL=3, lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=y,
+                          weights=w, theta=theta, z0=z0, u=u, z=z))
+    outs = ctx.run_batch(probs, want_final=True)
+    for o, r in zip(outs, refs):
+        assert abs(o["loglik"] - r["loglikelihood_estimate"]) < 1e-9
+        np.testing.assert_allclose(o["statistics"], r["statistics"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(o["mean_stat"], r["mean_statistic"], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal")])
+def test_n2_device_rng_and_f32(ctx, model, kernel):
+    """Device RNG (f64 and f32): the O(N^2) and O(N) Poyiadjis estimates of the same score agree
+    within Monte-Carlo error; errors (N > 1024, mixing smoothers in a batch) are reported."""
+    g = Golden("n2.npz")
+    m = [q for q in g.meta if q["model"] == model and q["kernel"] == kernel and q["stat"] == "score"][0]
+    rs = np.random.RandomState(3)
+    T = 30
+    y = rs.normal(size=T)
+    base = dict(model=model, kernel=kernel, stat="score", N=1000, t1=0, tL=T, lambduh=1.0, prior_mean=0.0,
+                prior_var=m["prior_var"], y=y, theta=g.get(m["key"], "theta"), rng="device", seed=5)
+    res = {}
+    for dtype in ("f64", "f32"):
+        for sm in ("poyiadjis_n2", "nemeth"):
+            outs = ctx.run_batch([dict(base, smoother=sm, dtype=dtype, stream=s) for s in range(8)])
+            res[(dtype, sm)] = np.array([o["mean_stat"] for o in outs])
+            assert np.all(np.isfinite(res[(dtype, sm)]))
+    for dtype in ("f64", "f32"):
+        a, b = res[(dtype, "poyiadjis_n2")], res[(dtype, "nemeth")]
+        sd = np.sqrt(a.var(axis=0) / 8 + b.var(axis=0) / 8) + 1e-3
+        ok = np.abs(a.mean(axis=0) - b.mean(axis=0)) < 6 * sd + 0.05 * np.abs(b.mean(axis=0))
+        if model == "garch":
+            # GARCH's state carries the deterministic sigma^2 component; the reference's backward
+            # kernel (garch/kernels.py:20-37) scores only the x component, so its O(N^2) (and PaRIS)
+            # estimates of the phi / lambda scores differ systematically from the O(N) ones -- the
+            # CPU oracle shows the same (+0.42, +0.24 vs -0.98, -0.09 on this series).  The device
+            # reproduces the reference (fixture test above); only the LRinv / mu columns must agree.
+            ok = ok[:2]
+        assert np.all(ok), (a.mean(0), b.mean(0))
+    # the O(N^2) estimator has the smaller variance (that is its point)
+    assert res[("f64", "poyiadjis_n2")].var(axis=0)[:2].sum() < res[("f64", "nemeth")].var(axis=0)[:2].sum() * 1.5
+    with pytest.raises(NotImplementedError):
+        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", N=2000, stream=1)])
+    with pytest.raises(ValueError):
+        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", stream=1),
+                       dict(base, smoother="nemeth", dtype="f64", stream=2)])

@@ -93,8 +93,6 @@ def test_paris_through_sampler_api():
     assert all(np.all(np.isfinite(v)) for v in g.values())
     with pytest.raises(NotImplementedError):
         sampler.noisy_gradient(kind="pf", pf="paris", N=5000)
-    with pytest.raises(NotImplementedError):
-        sampler.noisy_gradient(kind="pf", pf="poyiadjis_N2", N=100)
 
 
 def test_paris_f32_and_filter_stat(ctx):

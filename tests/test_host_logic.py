@@ -287,8 +287,6 @@ def test_unsupported_paths_raise():
     s = SVMSampler(n=1, m=1, observations=y, parameters=default_params("svm"))
     with pytest.raises(NotImplementedError):
         s.noisy_gradient(kind="marginal")
-    with pytest.raises(NotImplementedError):
-        s.noisy_gradient(kind="pf", pf="poyiadjis_N2", N=10)
     with pytest.raises(ValueError):
         s.noisy_gradient(kind="pf", pf="bogus", N=10)
     with pytest.raises(NotImplementedError):

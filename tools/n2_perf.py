@@ -1,0 +1,25 @@
+"""Timing of the O(N^2) Poyiadjis smoother kernel (device RNG): ms per launch for B windows."""
+import sys, time
+import numpy as np
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..",
+                "stochastic-gradient-mcmc-for-non-linear-state-models---mth422_amd"))
+from sgmcmc_ssm_amd import _capi
+
+ctx = _capi.default_context(0)
+rs = np.random.RandomState(0)
+for model, kernel, theta in (("svm", "prior", [0.95, 0.5 ** -0.5, 0.5 ** -0.5]),
+                             ("garch", "optimal", [np.log(2.0 / 3), np.log(0.85 / 0.15), np.log(0.8 / 0.05 * 0.05 / 0.05), 0.3 ** -0.5]),
+                             ("lgssm", "optimal", [0.9, 1.0, 0.7 ** -0.5, 1.0])):
+    for dtype in ("f64", "f32"):
+        for N, T, B in ((1000, 50, 1), (1000, 50, 512), (256, 50, 1024)):
+            y = rs.normal(size=T)
+            probs = [dict(model=model, kernel=kernel, smoother="poyiadjis_n2", stat="score", dtype=dtype, rng="device",
+                          N=N, t1=0, tL=T, lambduh=1.0, prior_mean=0.0, prior_var=1.0, y=y, theta=np.array(theta),
+                          seed=1, stream=b) for b in range(B)]
+            ctx.run_batch(probs)
+            t0 = time.perf_counter()
+            ctx.run_batch(probs)
+            dt = time.perf_counter() - t0
+            print("{0:6s} {1} N={2:5d} T={3} B={4:5d}: {5:8.2f} ms/launch, {6:7.1f} us per window-timestep (amortised), "
+                  "{7:6.2f} G pairs/s".format(model, dtype, N, T, B, dt * 1e3, dt * 1e6 / (T * B) , B * T * N * N / dt / 1e9),
+                  flush=True)
