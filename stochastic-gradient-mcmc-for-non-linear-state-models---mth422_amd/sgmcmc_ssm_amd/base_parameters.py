@@ -507,3 +507,80 @@ class BasePrior(object):
         for block in cls._blocks:
             block.from_parameters(out, parameters, var)
         return cls(**out)
+
+
+# ----------------------------------------------------------------------------------------
+# Preconditioners (SGRLD / SGRD): D(theta) per variable block
+# ----------------------------------------------------------------------------------------
+class MatrixPrecond(object):
+    """Matrix variable with row covariance `row_cov`: D = Q (x) I, noise = LQinv^-T z, no
+    correction (variables/matrices.py:632-656 square, :1099-1125 rectangular)."""
+
+    def __init__(self, name, row_cov):
+        self.name, self.row_cov = name, row_cov
+
+    def precondition(self, out, grad, parameters):
+        out[self.name] = np.dot(getattr(parameters, self.row_cov), grad[self.name])
+
+    def noise(self, out, parameters):
+        L = getattr(parameters, "L{0}inv".format(self.row_cov))
+        shape = np.shape(getattr(parameters, self.name))
+        out[self.name] = np.linalg.solve(L.T, np.random.normal(loc=0, size=shape))
+
+    def correction(self, out, parameters):
+        out[self.name] = np.zeros_like(getattr(parameters, self.name), dtype=float)
+
+
+class CholPrecisionPrecond(object):
+    """Cholesky factor of a precision: D = Qinv / 2, noise = sqrt(1/2) LQinv z, correction
+    (n + 1)/2 LQinv_vec (variables/covariance.py:286-317)."""
+
+    def __init__(self, name):
+        self.inv, self.vec = "{0}inv".format(name), "L{0}inv_vec".format(name)
+
+    def precondition(self, out, grad, parameters):
+        Qinv = getattr(parameters, self.inv)
+        G = np.zeros(Qinv.shape)
+        G[np.tril_indices_from(G)] = grad[self.vec]
+        P = np.dot(0.5 * Qinv, G)
+        out[self.vec] = P[np.tril_indices_from(P)]
+
+    def noise(self, out, parameters):
+        L = _tril_to_mat(getattr(parameters, self.vec))
+        Z = np.dot(np.sqrt(0.5) * L, np.random.normal(loc=0, size=L.shape))
+        out[self.vec] = Z[np.tril_indices_from(Z)]
+
+    def correction(self, out, parameters):
+        vec = getattr(parameters, self.vec)
+        n = int(np.sqrt(len(vec) * 2))
+        out[self.vec] = 0.5 * (n + 1) * vec
+
+
+class BasePreconditioner(object):
+    """precondition / precondition_noise / correction_term over the blocks, each scaled as the
+    reference scales them (base_parameters.py:260-297)."""
+    _blocks = ()
+
+    def precondition(self, grad, parameters, scale=1.0, **kwargs):
+        out = {}
+        for blk in self._blocks:
+            blk.precondition(out, grad, parameters)
+        for var in out:
+            out[var] = out[var] * scale
+        return out
+
+    def precondition_noise(self, parameters, scale=1.0):
+        out = {}
+        for blk in self._blocks:
+            blk.noise(out, parameters)
+        for var in out:
+            out[var] = out[var] * scale ** 0.5
+        return out
+
+    def correction_term(self, parameters, scale=1.0):
+        out = {}
+        for blk in self._blocks:
+            blk.correction(out, parameters)
+        for var in out:
+            out[var] = out[var] * scale
+        return out

@@ -8,7 +8,8 @@ Kalman (exact) code is not accelerated; its outputs serve as test fixtures."""
 import numpy as np
 
 from ..base_parameters import (BaseParameters, BasePrior, MatrixVar, CholPrecisionVar,
-                               WishartPrecisionPrior, MatrixNormalPrior, install_properties)
+                               WishartPrecisionPrior, MatrixNormalPrior, install_properties,
+                               BasePreconditioner, MatrixPrecond, CholPrecisionPrecond)
 from ..sgmcmc_sampler import SGMCMCSampler, SeqSGMCMCSampler, PFHelper
 from .svm import stationary_precision
 
@@ -34,6 +35,12 @@ class LGSSMPrior(BasePrior):
     _blocks = (WishartPrecisionPrior('Q', 'n'), WishartPrecisionPrior('R', 'm'),
                MatrixNormalPrior('A', ('n',), row_cov='Q'),
                MatrixNormalPrior('C', ('m', 'n'), row_cov='R'))
+
+
+class LGSSMPreconditioner(BasePreconditioner):
+    """SGRLD / SGRD preconditioner (lgssm/parameters.py:58-67); noise is drawn A, C, Q, R."""
+    _blocks = (MatrixPrecond('A', 'Q'), MatrixPrecond('C', 'R'),
+               CholPrecisionPrecond('Q'), CholPrecisionPrecond('R'))
 
 
 def generate_lgssm_data(T, parameters, initial_message=None, tqdm=None):
@@ -93,6 +100,9 @@ class LGSSMSampler(SGMCMCSampler):
             return
         if np.shape(observations)[1] != self.m:
             raise ValueError("observations second dimension does not match m")
+
+    def _get_preconditioner(self, preconditioner=None):
+        return LGSSMPreconditioner() if preconditioner is None else preconditioner
 
 
 class SeqLGSSMSampler(SeqSGMCMCSampler, LGSSMSampler):

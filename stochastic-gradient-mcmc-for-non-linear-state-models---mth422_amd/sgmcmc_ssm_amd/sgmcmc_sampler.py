@@ -392,16 +392,19 @@ class SGMCMCSampler(object):
     def noisy_gradient(self, preconditioner=None, is_scaled=True, **kwargs):
         """grad log-likelihood (particle filter, buffered) + grad log-prior, optionally / T
         (sgmcmc_sampler.py:427-464)."""
-        if preconditioner is not None:
-            raise NotImplementedError("preconditioned (SGRLD) steps are not on the PF path yet")
         kwargs.pop('tqdm', None)
         T_total = self._get_T(**kwargs)
         grad_loglike = self._noisy_grad_loglikelihood(**{k: v for k, v in kwargs.items() if k != 'T'})
         grad_prior = self.prior.grad_logprior(parameters=self.parameters)
         grad = {var: grad_prior[var] + grad_loglike[var] for var in grad_prior}
-        if is_scaled:
-            for var in grad:
-                grad[var] = grad[var] / T_total
+        if preconditioner is None:
+            if is_scaled:
+                for var in grad:
+                    grad[var] = grad[var] / T_total
+        else:
+            # sgmcmc_sampler.py:452-457: D(theta) * gradient, scaled by 1/T
+            grad = preconditioner.precondition(grad, parameters=self.parameters,
+                                               scale=(1.0 / T_total if is_scaled else 1.0))
         return grad
 
     def noisy_gradient_trace(self, parameters_list, is_scaled=True, **kwargs):
@@ -473,6 +476,8 @@ class SGMCMCSampler(object):
 
     def _get_sgmcmc_noise(self, is_scaled=True, preconditioner=None, **kwargs):
         scale = 1.0 / self._get_T(**kwargs) if is_scaled else 1.0
+        if preconditioner is not None:
+            return preconditioner.precondition_noise(parameters=self.parameters, scale=scale)
         return {var: np.random.normal(loc=0, scale=np.sqrt(scale), size=value.shape)
                 for var, value in self.parameters.as_dict().items()}
 
@@ -486,8 +491,29 @@ class SGMCMCSampler(object):
             self.parameters.var_dict[var] += epsilon * delta[var] + np.sqrt(2.0 * epsilon) * white_noise[var]
         return self.parameters
 
+    def step_precondition_sgd(self, epsilon, preconditioner, **kwargs):
+        """theta += eps * D(theta) noisy_gradient  (sgmcmc_sampler.py:486-502)."""
+        delta = self.noisy_gradient(preconditioner=preconditioner, **kwargs)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += epsilon * delta[var]
+        return self.parameters
+
     def sample_sgrld(self, epsilon, preconditioner, **kwargs):
-        raise NotImplementedError("SGRLD preconditioning is a 'next' row (SURVEY.md 8f)")
+        """theta += eps (D grad + correction) + sqrt(2 eps) N(0, D / T)  (sgmcmc_sampler.py:613-640).
+        The particle-filter gradient runs on the GPU; D(theta) is d = 1 host algebra."""
+        scale = 1.0 / self._get_T(**kwargs) if kwargs.get("is_scaled", True) else 1.0
+        delta = self.noisy_gradient(preconditioner=preconditioner, **kwargs)
+        white_noise = self._get_sgmcmc_noise(preconditioner=preconditioner, **kwargs)
+        correction = preconditioner.correction_term(self.parameters, scale=scale)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += (epsilon * (delta[var] + correction[var])
+                                              + np.sqrt(2.0 * epsilon) * white_noise[var])
+        return self.parameters
+
+    def _get_preconditioner(self, preconditioner=None):
+        if preconditioner is None:
+            raise NotImplementedError("No Default Preconditioner for {}".format(self.name))
+        return preconditioner
 
     def sample_gibbs(self):
         raise NotImplementedError()
@@ -502,7 +528,7 @@ class SGMCMCSampler(object):
         project_kwargs = kwargs.get("project_kwargs", {})
         if iter_type == 'custom':
             names, kws = kwargs.get("iter_func_names"), kwargs.get("iter_func_kwargs")
-        elif iter_type in ('SGD', 'ADAGRAD', 'SGLD'):
+        elif iter_type in ('SGD', 'ADAGRAD', 'SGLD', 'SGRD', 'SGRLD'):
             grad_kwargs = dict(epsilon=kwargs['epsilon'],
                                subsequence_length=kwargs['subsequence_length'],
                                buffer_length=kwargs['buffer_length'],
@@ -512,9 +538,12 @@ class SGMCMCSampler(object):
                                **kwargs.get("pf_kwargs", {}))
             if 'num_sequences' in kwargs:
                 grad_kwargs['num_sequences'] = kwargs['num_sequences']
-            step = dict(SGD='step_sgd', ADAGRAD='step_adagrad', SGLD='sample_sgld')[iter_type]
+            if iter_type in ('SGRD', 'SGRLD'):
+                grad_kwargs['preconditioner'] = self._get_preconditioner(kwargs.get('preconditioner'))
+            step = dict(SGD='step_sgd', ADAGRAD='step_adagrad', SGLD='sample_sgld',
+                        SGRD='step_precondition_sgd', SGRLD='sample_sgrld')[iter_type]
             names, kws = [step, 'project_parameters'], [grad_kwargs, project_kwargs]
-        elif iter_type in ('SGRD', 'SGRLD', 'Gibbs'):
+        elif iter_type == 'Gibbs':
             raise NotImplementedError("iter_type '{0}' is not on the particle-filter path".format(iter_type))
         else:
             raise ValueError("Unrecognized iter_type {0}".format(iter_type))

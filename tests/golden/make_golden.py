@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -550,6 +550,67 @@ def make_n2_fixtures():
     np.savez_compressed(os.path.join(HERE, "n2.npz"), **out)
 
 
+def make_sgrld_fixtures():
+    """SGRLD / SGRD with the LGSSM preconditioner on particle-filter gradients
+    (sgmcmc_sampler.py:486-502, 613-640; covariance.py:286-317; matrices.py:632-656, 1099-1125)."""
+    from sgmcmc_ssm.models.lgssm import LGSSMPreconditioner
+    out, meta = {}, []
+    np.random.seed(333)
+    y = generate_lgssm_data(T=150, parameters=lgssm_params())["observations"]
+    out["y"] = y.reshape(-1)
+    for ci, (S, B, N, is_scaled) in enumerate([(-1, -1, 100, True), (16, 4, 150, True), (20, 3, 80, False)]):
+        kw = dict(kind="pf", pf="poyiadjis_N", N=N, subsequence_length=S, buffer_length=B, minibatch_size=1)
+        key = "sgrld{0}".format(ci)
+        sampler = LGSSMSampler(n=1, m=1, observations=y, parameters=lgssm_params())
+        pre = LGSSMPreconditioner()
+        np.random.seed(700 + ci)
+        g = sampler.noisy_gradient(preconditioner=pre, is_scaled=is_scaled, **kw)
+        out[key + "/precond_gradient"] = as_vec("lgssm", g)
+        np.random.seed(710 + ci)
+        traj = [theta_of("lgssm", sampler.parameters)]
+        for _ in range(4):
+            sampler.sample_sgrld(epsilon=0.05, preconditioner=pre, is_scaled=is_scaled, **kw)
+            traj.append(theta_of("lgssm", sampler.parameters))
+            sampler.project_parameters()
+            traj.append(theta_of("lgssm", sampler.parameters))
+        out[key + "/sgrld_traj"] = np.array(traj)
+        sampler = LGSSMSampler(n=1, m=1, observations=y, parameters=lgssm_params())
+        np.random.seed(720 + ci)
+        traj = [theta_of("lgssm", sampler.parameters)]
+        for _ in range(3):
+            sampler.step_precondition_sgd(epsilon=0.05, preconditioner=pre, is_scaled=is_scaled, **kw)
+            sampler.project_parameters()
+            traj.append(theta_of("lgssm", sampler.parameters))
+        out[key + "/sgrd_traj"] = np.array(traj)
+        for it in ("SGRLD", "SGRD"):
+            sampler = LGSSMSampler(n=1, m=1, observations=y, parameters=lgssm_params())
+            np.random.seed(730 + ci)
+            plist = sampler.fit(iter_type=it, num_iters=3, output_all=True, epsilon=0.02, subsequence_length=S,
+                                buffer_length=B, kind="pf", pf_kwargs=dict(pf="poyiadjis_N", N=N))
+            out[key + "/fit_" + it] = np.array([theta_of("lgssm", q) for q in plist])
+        meta.append(dict(key=key, S=S, B=B, N=N, is_scaled=is_scaled))
+    seqs = [y[0:60], y[60:95], y[95:150]]
+    seq = SeqLGSSMSampler(n=1, m=1, observations=seqs, parameters=lgssm_params())
+    np.random.seed(741)
+    plist = seq.fit(iter_type="SGRLD", num_iters=3, output_all=True, epsilon=0.02, subsequence_length=16,
+                    buffer_length=4, kind="pf", num_sequences=2, pf_kwargs=dict(pf="poyiadjis_N", N=90))
+    out["seq/fit_SGRLD"] = np.array([theta_of("lgssm", q) for q in plist])
+    # no default preconditioner for SVM / GARCH (sgmcmc_sampler.py:949-953)
+    errs = {}
+    for name, Sampler, mk, gen in (("svm", SVMSampler, svm_params, generate_svm_data),
+                                   ("garch", GARCHSampler, garch_params, generate_garch_data)):
+        np.random.seed(1)
+        sm = Sampler(n=1, m=1, observations=gen(T=30, parameters=mk())["observations"], parameters=mk())
+        try:
+            sm.fit(iter_type="SGRLD", num_iters=1, epsilon=0.1, subsequence_length=-1, buffer_length=-1, kind="pf")
+            errs[name] = "ok"
+        except Exception as e:
+            errs[name] = type(e).__name__
+    out["errors"] = np.array(json.dumps(errs))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "sgrld.npz"), **out)
+
+
 def make_ksd_fixtures():
     """IMQ kernel Stein discrepancy of the reference (trace_metric_functions.py:20-81)."""
     from sgmcmc_ssm.trace_metric_functions import IMQ_KSD
@@ -577,6 +638,8 @@ if __name__ == "__main__":
         make_sampler_fixtures()
     if only in ("", "ksd"):
         make_ksd_fixtures()
+    if only in ("", "sgrld"):
+        make_sgrld_fixtures()
     if only in ("", "n2"):
         make_n2_fixtures()
     if only in ("", "paris"):

@@ -5,7 +5,7 @@ parallel-sum order only; the bar in BASELINE.json is gradient L2 error < 1e-4)."
 import numpy as np
 import pytest
 
-from test_host_logic import (_check_predictive, _check_sampler_case, _check_seq_and_minibatch, default_params,
+from test_host_logic import (_check_predictive, _check_sgrld, _check_sampler_case, _check_seq_and_minibatch, default_params,
                              vec)
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +44,11 @@ def test_predictive_device_rng_gpu(dtype):
     got = sampler.predictive_loglikelihood(kind="pf", num_steps_ahead=3, N=4000, rng="device", dtype=dtype)
     assert got.shape == (4,) and np.all(np.isfinite(got))
     np.testing.assert_allclose(got, ref, atol=1.5, rtol=0.02)
+
+
+def test_sgrld_gpu():
+    """SGRLD / SGRD trajectories (LGSSM preconditioner) with the gradients from the HIP kernels."""
+    _check_sgrld(exact=False, rtol=RTOL)
 
 
 def test_helper_known_answer_gpu(golden_window):

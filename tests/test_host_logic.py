@@ -268,6 +268,66 @@ def test_predictive_loglikelihood_matches_reference(oracle_backend, model):
     _check_predictive(model, exact=True)
 
 
+def _check_sgrld(exact=True, rtol=0.0):
+    """SGRLD / SGRD (LGSSM preconditioner) on particle-filter gradients vs the reference
+    trajectories (tests/golden/sgrld.npz)."""
+    import json
+    from conftest import Golden
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMPreconditioner
+    g = Golden("sgrld.npz")
+    cmp = (np.testing.assert_array_equal if exact else
+           (lambda a, b: np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol)))
+    Sampler, SeqSampler = SAMPLERS["lgssm"]
+    y = g["y"].reshape(-1, 1)
+    for ci, m in enumerate(g.meta):
+        kw = dict(kind="pf", pf="poyiadjis_N", N=m["N"], subsequence_length=m["S"], buffer_length=m["B"],
+                  minibatch_size=1)
+        key = m["key"]
+        sampler = Sampler(n=1, m=1, observations=y, parameters=default_params("lgssm"))
+        pre = LGSSMPreconditioner()
+        np.random.seed(700 + ci)
+        cmp(vec("lgssm", sampler.noisy_gradient(preconditioner=pre, is_scaled=m["is_scaled"], **kw)),
+            g[key + "/precond_gradient"])
+        np.random.seed(710 + ci)
+        traj = [sampler.parameters.theta()]
+        for _ in range(4):
+            sampler.sample_sgrld(epsilon=0.05, preconditioner=pre, is_scaled=m["is_scaled"], **kw)
+            traj.append(sampler.parameters.theta())
+            sampler.project_parameters()
+            traj.append(sampler.parameters.theta())
+        cmp(np.array(traj), g[key + "/sgrld_traj"])
+        sampler = Sampler(n=1, m=1, observations=y, parameters=default_params("lgssm"))
+        np.random.seed(720 + ci)
+        traj = [sampler.parameters.theta()]
+        for _ in range(3):
+            sampler.step_precondition_sgd(epsilon=0.05, preconditioner=pre, is_scaled=m["is_scaled"], **kw)
+            sampler.project_parameters()
+            traj.append(sampler.parameters.theta())
+        cmp(np.array(traj), g[key + "/sgrd_traj"])
+        for it in ("SGRLD", "SGRD"):
+            sampler = Sampler(n=1, m=1, observations=y, parameters=default_params("lgssm"))
+            np.random.seed(730 + ci)
+            plist = sampler.fit(iter_type=it, num_iters=3, output_all=True, epsilon=0.02,
+                                subsequence_length=m["S"], buffer_length=m["B"], kind="pf",
+                                pf_kwargs=dict(pf="poyiadjis_N", N=m["N"]))
+            cmp(np.array([q.theta() for q in plist]), g[key + "/fit_" + it])
+    seq = SeqSampler(n=1, m=1, observations=[y[0:60], y[60:95], y[95:150]], parameters=default_params("lgssm"))
+    np.random.seed(741)
+    plist = seq.fit(iter_type="SGRLD", num_iters=3, output_all=True, epsilon=0.02, subsequence_length=16,
+                    buffer_length=4, kind="pf", num_sequences=2, pf_kwargs=dict(pf="poyiadjis_N", N=90))
+    cmp(np.array([q.theta() for q in plist]), g["seq/fit_SGRLD"])
+    # SVM / GARCH have no default preconditioner in the reference either
+    assert json.loads(str(g["errors"])) == dict(svm="NotImplementedError", garch="NotImplementedError")
+    for model in ("svm", "garch"):
+        sm = SAMPLERS[model][0](n=1, m=1, observations=np.zeros((30, 1)), parameters=default_params(model))
+        with pytest.raises(NotImplementedError):
+            sm.fit(iter_type="SGRLD", num_iters=1, epsilon=0.1, subsequence_length=-1, buffer_length=-1, kind="pf")
+
+
+def test_sgrld_matches_reference(oracle_backend):
+    _check_sgrld(exact=True)
+
+
 def test_helper_known_answer(oracle_backend, golden_window):
     """Helper.pf_gradient_estimate on the SVM T=1000 N=1000 case."""
     from sgmcmc_ssm_amd.models.svm import SVMHelper
