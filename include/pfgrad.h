@@ -50,7 +50,8 @@ enum pfg_model { PFG_MODEL_SVM = 0, PFG_MODEL_GARCH = 1, PFG_MODEL_LGSSM = 2 };
 enum pfg_kernel { PFG_KERNEL_PRIOR = 0, PFG_KERNEL_OPTIMAL = 1 };
 /* smoothers: particle_filters/pf.py:138-181 (nemeth; poyiadjis_N = lambduh 1.0), :40-82 (filter),
  * :183-341 (PaRIS: Ntilde backward-sampled parents per child by accept-reject, exact
- * categorical fallback after max_accept_reject rounds; N <= 1024) */
+ * categorical fallback after max_accept_reject rounds; N <= 1024 LDS-resident, up to 16384 in
+ * the large-N kernel through pfg_run / pfg_run_batch, which size its scratch) */
 enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTHER_PARIS = 2,
                     /* EXTENSION (not in the reference, which resamples multinomially every step,
                      * pf.py:26-30): NEMETH with systematic resampling, u_i = (i + u0)/N with ONE

@@ -1207,9 +1207,12 @@ __host__ __device__ constexpr int mem_rec_len() {
     constexpr int per = 16 / (int)sizeof(REAL);
     return (ModelDims<MODEL>::NS + ModelDims<MODEL>::H + per - 1) / per * per;
 }
+// PaRIS adds: the children's log-weights (the parents' stay readable for the exact fallback),
+// the fallback queue (child, result: int32 each) and its uniforms
 template <int MODEL, typename REAL>
-__host__ __device__ inline size_t mem_kernel_scratch_bytes(int N) {
-    return (size_t)N * sizeof(REAL) * (1 + 2 * mem_rec_len<MODEL, REAL>()) + 16;
+__host__ __device__ inline size_t mem_kernel_scratch_bytes(int N, bool paris = false) {
+    return (size_t)N * sizeof(REAL) * (1 + 2 * mem_rec_len<MODEL, REAL>()) + 16 +
+           (paris ? (size_t)N * (2 * sizeof(REAL) + 8) + 16 : 0);
 }
 template <int REC, typename REAL>
 __device__ __forceinline__ void rec_load(REAL *dst, const REAL *src) {
@@ -1232,7 +1235,7 @@ __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
            (size_t)(PFG_MAX_PRED * MEM_NW + MEM_NW + 2 * PFG_MAX_PRED) * 8 + tab_bytes<REAL, RNG, true>();
 }
 
-template <int MODEL, int KERNEL, typename REAL, int RNG>
+template <int MODEL, int KERNEL, typename REAL, int RNG, bool PARIS = false>
 __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     const int np2 = mem_np2(N);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
     const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : P.lambduh;
+    const double lam_d = is_filter ? 0.0 : (PARIS ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const double *__restrict__ const yv = P.y;
@@ -1274,6 +1277,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     // records start 16-byte aligned behind the log-weights
     REAL *cur = reinterpret_cast<REAL *>((reinterpret_cast<uintptr_t>(lwg + N) + 15) & ~(uintptr_t)15);   // [N][REC]
     REAL *nxt = cur + (size_t)REC * N;
+    // PaRIS extras behind the two record buffers: children's log-weights, fallback queue
+    REAL *lwn_g = reinterpret_cast<REAL *>((reinterpret_cast<uintptr_t>(cur + 2 * (size_t)REC * N) + 15) & ~(uintptr_t)15);
+    REAL *qum = lwn_g + N;                                           // [N] fallback uniforms
+    int *qchild = reinterpret_cast<int *>(qum + N);                  // [N]
+    int *qres = qchild + N;                                          // [N]
+    int *qcount = reinterpret_cast<int *>(red_W + 1);                // LDS
     // predictive: the statistic of the newest step, [lead k][particle]; folded into predv by the
     // NEXT iteration's normalisation (its weights are log_normalize(new_logw), pf.py:72-76)
     const bool predictive = (stat == PFG_STAT_PREDICTIVE);
@@ -1580,8 +1589,206 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 }
             }
         };
-        if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
-        else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+        // PaRIS for N > 1024 (pf.py:183-341): as pf_reg_kernel's paris_slots, with the particle state
+        // in the L2-resident scratch.  Per backward draw: accept-reject rounds per child against the
+        // filter CDF; children that never accept queue up and are served one per wave by an exact
+        // categorical draw over all parents (chunk sums kept one per lane, index order preserved).
+        auto paris_sweep = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            const int Nt = P.Ntilde, R = P.max_accept_reject;
+            const double *__restrict__ const pidx = P.paris_idx_u;
+            const double *__restrict__ const pacc = P.paris_acc_u;
+            const double *__restrict__ const pman = P.paris_man_u;
+            auto search = [&](double u) {
+                int pos = 0;
+                for (int step = np2 >> 1; step >= 1; step >>= 1) {
+                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                    pos += (cdf[pos + probe] <= u) ? step + (step >> 5) : 0;
+                }
+                int a = pos - pos / 33;
+                return a < N - 1 ? a : N - 1;
+            };
+            // ---- 1. propose every child from its filter ancestor, publish x' and log-weight ----
+            for (int j = 0; j < nchunk; ++j) {
+                const int i = j * NT + tid;
+                const bool v = i < N;
+                const int ii = v ? i : N - 1;
+                double u;
+                REAL z;
+                if (RNG == PFG_RNG_REPLAY) { u = uv[(size_t)t * N + ii]; z = (REAL)zv[(size_t)t * N + ii]; }
+                else { REAL zb; u = u01_32(rng.next()); mth.normal_pair(rng.next(), rng.next(), z, zb); }
+                const int a = search(u);
+                if (RNG == PFG_RNG_REPLAY && v) {
+                    const double hi = cdf[cdf_phys(a)] - u;
+                    const double lo = a > 0 ? u - cdf[cdf_phys(a - 1)] : 1.0;
+                    const double mg = hi < lo ? hi : lo;
+                    tie = mg < tie ? mg : tie;
+                }
+                REAL xp[NS], xn[NS], add[H], lwn;
+                alignas(16) REAL rec[REC];
+                rec_load<REC, REAL>(rec, cur + (size_t)a * REC);
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = rec[d];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z, xn, lwn, add);
+                if (v) {
+                    lwn_g[i] = lwn;
+#pragma unroll
+                    for (int q = 0; q < REC; ++q) rec[q] = (REAL)0;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) rec[d] = xn[d];
+                    rec_store<REC, REAL>(nxt + (size_t)i * REC, rec);
+                    if (P.trace_x && P.trace_anc) P.trace_anc[(size_t)t * N + i] = a;
+                }
+            }
+            __syncthreads();
+            // contribution of parent J to child ci:  stats[J] + w_t h(x_J, x_ci), added to the child's record
+            auto contribute = [&](int ci, int J) {
+                alignas(16) REAL rc[REC], rp[REC];
+                rec_load<REC, REAL>(rc, nxt + (size_t)ci * REC);
+                rec_load<REC, REAL>(rp, cur + (size_t)J * REC);
+                const REAL aux = (MODEL == PFG_MODEL_SVM) ? mth.exp(-rc[0]) : (REAL)0;
+                REAL aj[H];
+                additive_stat<MODEL, STAT, REAL>(c, rp, rc, (REAL)y_t, aux, aj);
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                    rc[NS + h] += rp[NS + h] + a;
+                }
+                rec_store<REC, REAL>(nxt + (size_t)ci * REC, rc);
+            };
+            for (int jt = 0; jt < Nt; ++jt) {
+                if (tid == 0) *qcount = 0;
+                __syncthreads();
+                // ---- 2. accept-reject against the filter weights, R rounds per child ------------
+                for (int j = 0; j < nchunk; ++j) {
+                    const int i = j * NT + tid;
+                    const bool v = i < N;
+                    const int ii = v ? i : N - 1;
+                    REAL xn[NS];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xn[d] = nxt[(size_t)ii * REC + d];
+                    int J = -1;
+                    for (int r = 0; r < R; ++r) {
+                        const bool pend = v && J < 0;
+                        if (!__any(pend)) break;
+                        double u1, u2;
+                        if (RNG == PFG_RNG_REPLAY) {
+                            const size_t at = (((size_t)t * Nt + jt) * R + r) * N + ii;
+                            u1 = pidx[at]; u2 = pacc[at];
+                        } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
+                        const int I = search(u1);
+                        REAL xI[NS];
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)I * REC + d];
+                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn));
+                        if (pend && u2 <= thr) J = I;
+                    }
+                    if (v) {
+                        if (J >= 0) contribute(i, J);
+                        else {
+                            const int e = atomicAdd(qcount, 1);
+                            qchild[e] = i;
+                            qum[e] = (REAL)((RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + jt) * N + i]
+                                                                     : u01_32(rng.next()));
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nq = *qcount;
+                // ---- 3. exact categorical draw for the queued children, one child per wave -------
+                const int nch64 = (N + WAVE - 1) / WAVE;           // <= 256: chunk sums kept [4] per lane
+                for (int e = wave; e < nq; e += NW) {
+                    const int ci = qchild[e];
+                    REAL xc[NS];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)ci * REC + d];
+                    const double um = (double)qum[e];
+                    auto logit = [&](int q) {
+                        REAL xq[NS];
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)q * REC + d];
+                        return lwg[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc);
+                    };
+                    float mxf = -INFINITY;
+                    for (int q = lane; q < N; q += WAVE) mxf = fmaxf(mxf, (float)logit(q));
+                    const REAL mm = (REAL)wave_max(mxf);
+                    double keep[4] = {0.0, 0.0, 0.0, 0.0};        // chunk s*64 + lane lives in keep[s]
+                    double tot = 0.0;
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) {
+                        for (int cl = 0; cl < WAVE; ++cl) {
+                            const int ch = sI * WAVE + cl;
+                            if (ch >= nch64) break;
+                            const int q = ch * WAVE + lane;
+                            const double ev = q < N ? (double)mth.exp((REAL)(logit(q < N ? q : N - 1) - mm)) : 0.0;
+                            const double cs = wave_sum(ev);
+                            keep[sI] = (lane == cl) ? cs : keep[sI];
+                            tot += cs;
+                        }
+                    }
+                    const double target = um * tot;
+                    // chunk holding the target: first chunk whose inclusive running sum exceeds it
+                    int nle = 0;
+                    double base = 0.0, before = 0.0;
+                    double incs[4];
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) {
+                        const double inc = wave_incl_scan(keep[sI]) + base;
+                        incs[sI] = inc;
+                        const bool validc = (sI * WAVE + lane) < nch64;
+                        nle += (validc && inc <= target) ? 1 : 0;
+                        base = bcast_lane63(inc);
+                    }
+                    int msel = (int)wave_sum((double)nle);
+                    msel = msel < nch64 - 1 ? msel : nch64 - 1;
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) {
+                        const bool here = (sI * WAVE + lane) == msel;
+                        before += here ? incs[sI] - keep[sI] : 0.0;
+                    }
+                    before = wave_sum(before);
+                    const int q = msel * WAVE + lane;
+                    const double ev = q < N ? (double)mth.exp((REAL)(logit(q < N ? q : N - 1) - mm)) : 0.0;
+                    const double inc = wave_incl_scan(ev) + before;
+                    int cnt = (q < N && inc <= target) ? 1 : 0;
+                    cnt = msel * WAVE + (int)wave_sum((double)cnt);
+                    if (lane == 0) qres[e] = cnt < N - 1 ? cnt : N - 1;
+                }
+                __syncthreads();
+                // ---- 4. queued children: rewired parent's contribution ---------------------------
+                for (int e = tid; e < nq; e += NT) contribute(qchild[e], qres[e]);
+                __syncthreads();
+            }
+            // ---- 5. average over the Ntilde draws, traces -----------------------------------------
+            for (int j = 0; j < nchunk; ++j) {
+                const int i = j * NT + tid;
+                if (i < N) {
+                    alignas(16) REAL rc[REC];
+                    rec_load<REC, REAL>(rc, nxt + (size_t)i * REC);
+#pragma unroll
+                    for (int h = 0; h < H; ++h) rc[NS + h] = rc[NS + h] / (REAL)Nt;
+                    rec_store<REC, REAL>(nxt + (size_t)i * REC, rc);
+                    if (P.trace_x) {
+                        const size_t row = (size_t)(t + 1) * N + i;
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)rc[d];
+                        P.trace_logw[row] = (double)lwn_g[i];
+                        if (P.trace_stats) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)rc[NS + h];
+                        }
+                    }
+                }
+            }
+            { REAL *tmp = lwg; lwg = lwn_g; lwn_g = tmp; }
+        };
+        if constexpr (PARIS) {
+            if (stat == PFG_STAT_SCORE) paris_sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else paris_sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+        } else {
+            if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+        }
         { REAL *tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
         nact_prev = nact;

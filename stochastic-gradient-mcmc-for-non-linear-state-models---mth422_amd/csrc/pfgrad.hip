@@ -104,10 +104,10 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
     return -1;
 }
 
-size_t scratch_bytes(int model, int dtype, int N) {
+size_t scratch_bytes(int model, int dtype, int N, bool paris = false) {
     const size_t rs = dtype == PFG_F64 ? 8 : 4, per = 16 / rs;
     const size_t rec = (state_dim(model) + stat_dim(model) + per - 1) / per * per;   // pfg::mem_rec_len
-    return (size_t)N * rs * (1 + 2 * rec) + 16;
+    return (size_t)N * rs * (1 + 2 * rec) + 16 + (paris ? (size_t)N * (2 * rs + 8) + 16 : 0);   // pfg::mem_kernel_scratch_bytes
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
@@ -152,7 +152,18 @@ template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     if (n_max <= 256) return launch_paris_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
     if (n_max <= 1024) return launch_paris_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
-    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
+    if (n_max > pfg::MEM_MAX_N)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 16384 (N = " + std::to_string(n_max) + ")");
+    // large-N kernel, PaRIS instantiation (state in the HBM scratch; descriptors must carry one)
+    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, true>;
+    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
 }
 
 constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5;
@@ -637,8 +648,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
     size_t n_scratch = 0;                  // bytes; every window of the batch gets n_max-sized state
     const size_t pred_each = predictive ? ((size_t)n_max * PFG_MAX_PRED * (dtype == PFG_F64 ? 8 : 4) + 255) / 256 * 256 : 0;
-    const size_t scratch_each = (scratch_bytes(model, dtype, n_max) + 255) / 256 * 256 + pred_each;
-    if (variant == kVariantMem) n_scratch = scratch_each * (size_t)B;
+    const bool paris_mem = paris && n_max > 1024;
+    const size_t scratch_each = (scratch_bytes(model, dtype, n_max, paris_mem) + 255) / 256 * 256 + pred_each;
+    if (variant == kVariantMem || paris_mem) n_scratch = scratch_each * (size_t)B;
 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     PFG_HIP(ctx, ctx->in.ensure(n_in * 8));

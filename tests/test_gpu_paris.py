@@ -51,6 +51,38 @@ def test_paris_pool_parity(ctx, model, kernel, N, Ntilde, R):
     assert abs(o["loglik"] - ref["loglikelihood_estimate"]) <= ATOL + RTOL * abs(ref["loglikelihood_estimate"])
 
 
+@pytest.mark.parametrize("model,kernel", CASES)
+@pytest.mark.parametrize("N,Ntilde,R", [(1100, 2, 4), (2500, 1, 0), (4099, 2, 2)])
+def test_paris_large_n_pool_parity(ctx, model, kernel, N, Ntilde, R):
+    """N > 1024: the large-N kernel's PaRIS instantiation (state in the HBM scratch, chunked
+    exact fallback) against the oracle on identical uniform pools."""
+    rs = np.random.RandomState(N + Ntilde)
+    T, t1, tL = 4, 1, 4
+    p = default_params(model)
+    np.random.seed(5)
+    y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
+    w = rs.uniform(1.0, 5.0, size=tL - t1)
+    z0, u, z = po.draw_streams(rs, N, T)
+    idx_u = rs.random_sample((T, Ntilde, max(R, 1), N))[:, :, :R]
+    acc_u = rs.random_sample((T, Ntilde, max(R, 1), N))[:, :, :R]
+    man_u = rs.random_sample((T, Ntilde, N))
+    pv = 1.3
+    ref = po.pf_window(model, p.theta(), y, N, z0, u, z, kernel=kernel, pf="paris", stat="score", t1=t1, tL=tL,
+                       weights=w, prior_mean=0.0, prior_var=pv, save_all=True, Ntilde=Ntilde,
+                       max_accept_reject=R, manual_sample_threshold=0,
+                       paris_draws=po.PoolDraws(idx_u, acc_u, man_u))
+    q = dict(model=model, kernel=kernel, smoother="paris", stat="score", dtype="f64", rng="replay", N=N, t1=t1,
+             tL=tL, prior_mean=0.0, prior_var=pv, y=y, weights=w, theta=p.theta(), z0=z0, u=u, z=z,
+             Ntilde=Ntilde, max_accept_reject=R, paris_idx_u=np.ascontiguousarray(idx_u),
+             paris_acc_u=np.ascontiguousarray(acc_u), paris_man_u=man_u)
+    o = ctx.run_batch([q], want_trace=True)[0]
+    np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["all_log_weights"], ref["all_log_weights"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["all_statistics"], ref["all_statistics"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8)
+    assert abs(o["loglik"] - ref["loglikelihood_estimate"]) <= ATOL + RTOL * abs(ref["loglikelihood_estimate"])
+
+
 @pytest.mark.parametrize("model", ["svm", "garch"])
 def test_paris_device_rng_statistics(ctx, model):
     """Device-RNG PaRIS (Helper API, default settings) vs the reference-order oracle:
@@ -64,7 +96,7 @@ def test_paris_device_rng_statistics(ctx, model):
     pm, pv = (0.0, 10.0) if model == "svm" else (0.0, float(po.garch_prior_x(p.theta())[1][0]))
     probs = [make_problem(model, kernel, "paris", y, p.theta(), N, prior_mean=pm, prior_var=pv, seed=5, stream=b)
              for b in range(B)]
-    assert probs[0]["rng"] == "device" and probs[0]["max_accept_reject"] == 16
+    assert probs[0]["rng"] == "device" and probs[0]["max_accept_reject"] == 32
     outs = ctx.run_batch(probs)
     got = np.array([np.append(o["mean_stat"], o["loglik"]) for o in outs])
     rs = np.random.RandomState(1)
@@ -91,8 +123,10 @@ def test_paris_through_sampler_api():
     assert np.isfinite(lj["logjoint"]) and np.isfinite(lj["loglikelihood"])
     g = sampler.noisy_gradient(kind="pf", pf="paris", N=200, subsequence_length=16, buffer_length=4)
     assert all(np.all(np.isfinite(v)) for v in g.values())
+    g = sampler.noisy_gradient(kind="pf", pf="paris", N=5000, subsequence_length=16, buffer_length=4)
+    assert all(np.all(np.isfinite(v)) for v in g.values())          # large-N kernel, PaRIS instantiation
     with pytest.raises(NotImplementedError):
-        sampler.noisy_gradient(kind="pf", pf="paris", N=5000)
+        sampler.noisy_gradient(kind="pf", pf="paris", N=20000)
 
 
 def test_paris_f32_and_filter_stat(ctx):
