@@ -546,6 +546,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
 
     constexpr bool FAST = fast_layout(NT, PP);
     constexpr bool TAB = FAST;
+    // Device RNG only: the CDF is built in THREAD-major order (position tid*PPT + k <-> particle
+    // k*NT + tid).  Multinomial resampling does not care how particles are labelled, and in this
+    // order a thread's PPT weights are contiguous: one in-register prefix + ONE wave scan per
+    // thread instead of PPT wave scans.  REPLAY keeps the reference's index order (parity).
+    constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
+    constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : 3));
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
     // binary search probes at power-of-two strides, which would otherwise all hit one LDS bank
     // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).
@@ -689,10 +695,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 if (lane == 0) red_S[h * NW + wave] = part;
             }
         }
+        if (BLK) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            cs[k] = wave_incl_scan(cs[k]);
-            if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
+            for (int k = 1; k < PPT; ++k) cs[k] += cs[k - 1];
+            const double inc = wave_incl_scan(cs[PPT - 1]);
+            const double exc = inc - cs[PPT - 1];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cs[k] += exc;
+            if (lane == WAVE - 1) red_scan[wave] = inc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                cs[k] = wave_incl_scan(cs[k]);
+                if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
+            }
         }
         if (RNG != PFG_RNG_REPLAY && systematic && tid == 0) red_W0[0] = u01_32(rng.next());
         // this step's randomness: REPLAY loads are issued here so that their latency overlaps the
@@ -707,7 +723,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
             }
         }
         __syncthreads();                                                        // barrier 2
-        if (PPT * NW <= 16) {
+        if (BLK) {
+            // NW wave totals: exclusive prefix by a DPP scan over the first lanes
+            const double tot = (lane < NW) ? red_scan[lane] : 0.0;
+            double inc = tot;
+            inc += dpp_shr0_f64<0x111>(inc);
+            inc += dpp_shr0_f64<0x112>(inc);
+            if (NW > 4) { inc += dpp_shr0_f64<0x114>(inc); inc += dpp_shr0_f64<0x118>(inc); }
+            const double exc = inc - tot;
+            const double off = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), wave),
+                                                __builtin_amdgcn_readlane(__double2loint(exc), wave));
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cs[k] += off;
+            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), NW - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(inc), NW - 1));
+        } else if (PPT * NW <= 16) {
             // lane j < PPT*NW holds total j; exclusive prefix by a 16-lane DPP scan; each thread
             // picks its PPT offsets and the grand total with v_readlane (uniform indices)
             double tot = (lane < PPT * NW) ? red_scan[lane] : 0.0;
@@ -767,12 +797,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         const double wt = (inside && wv) ? wv[t - t1] : 1.0;
         const bool use_stat = inside && (stat != PFG_STAT_NONE);
         const bool plain = !needS_every;                 // not filter and lambda == 1
+        if (BLK) {
+            // all PPT positions: slots beyond N carry weight 0 (flat CDF, never selected)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (valid[k]) {
-                cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
-                if (PARIS || N2) lwL[k * NT + tid] = lw[k];
-            }
+            for (int k = 0; k < PPT; ++k) cdf[cdf_phys(tid * PPT + k)] = cs[k] * invW;
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (valid[k]) {
+                    cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
+                    if (PARIS || N2) lwL[k * NT + tid] = lw[k];
+                }
+        }
         __syncthreads();                                                        // barrier 3
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
@@ -803,6 +839,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
             }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 8192)
+            if (BLK) {
+                // CDF position -> particle index
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) anc[k] = (anc[k] & (PPT - 1)) * NT + (anc[k] >> LOG_PPT);
+            }
         } else {
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
 #pragma unroll
