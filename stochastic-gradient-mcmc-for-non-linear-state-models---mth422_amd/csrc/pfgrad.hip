@@ -166,7 +166,27 @@ int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
     return PFG_OK;
 }
 
-constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5;
+constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
+
+// large-N kernel, device-RNG fast path (thread-major CDF, unrolled search, two chunks in flight)
+template <int MODEL, int KERNEL, typename REAL, int NP2>
+int launch_big_one(pfg_ctx *ctx, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_big_kernel<MODEL, KERNEL, REAL, NP2>;
+    size_t lds = pfg::big_kernel_lds_bytes<REAL>(NP2);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL>
+int launch_big(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 4096) return launch_big_one<MODEL, KERNEL, REAL, 4096>(ctx, B, dp, st);
+    return launch_big_one<MODEL, KERNEL, REAL, 16384>(ctx, B, dp, st);
+}
 
 // O(N^2) Poyiadjis smoother instantiations (ping-pong variants, parents' log-weights in LDS)
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
@@ -229,6 +249,10 @@ int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const p
         if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
         return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
     }
+    if (v == kVariantBig) {
+        if (dtype == PFG_F64) return launch_big<MODEL, KERNEL, double>(ctx, n_max, B, dp, st);
+        return launch_big<MODEL, KERNEL, float>(ctx, n_max, B, dp, st);
+    }
     if (v == kVariantN2) {
         if (dtype == PFG_F64) {
             if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
@@ -287,6 +311,12 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
+    // N > 1024 with the device generator: the fast large-N kernel, unless the statistic needs the
+    // general one (predictive) or PFGRAD_VARIANT=mem1024 asks for it (A/B timing, tests)
+    if (v == kVariantMem && rng == PFG_RNG_DEVICE && !force_mem) {
+        const char *force = std::getenv("PFGRAD_VARIANT");
+        if (!(force && !std::strcmp(force, "mem1024"))) v = kVariantBig;
+    }
     if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
     if (model == PFG_MODEL_GARCH) {
         if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
@@ -468,6 +498,10 @@ int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N) {
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max) {
     (void)kernel; (void)rng;
     int v = pick_variant(model, dtype, rng, n_max);
+    if (v == kVariantMem && rng == PFG_RNG_DEVICE) {
+        const char *force = std::getenv("PFGRAD_VARIANT");
+        if (!(force && !std::strcmp(force, "mem1024"))) return n_max <= 4096 ? "big4096" : "big16384";
+    }
     return v == kVariantMem ? "mem1024" : (v < 0 ? "none" : kVariants[v].tag);
 }
 

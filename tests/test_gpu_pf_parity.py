@@ -254,3 +254,49 @@ def test_f32_whole_run_statistics(ctx):
     se = np.sqrt(a.var(axis=0) / B + b.var(axis=0) / B)
     zs = np.abs(a.mean(axis=0) - b.mean(axis=0)) / se
     assert np.all(zs < 5.0), zs
+
+
+@pytest.mark.parametrize("model,kernel,theta", [("svm", "prior", [0.95, 1.4, 1.4]),
+                                                ("garch", "optimal", [0.0, 2.0, 2.0, 1.8]),
+                                                ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0])])
+@pytest.mark.parametrize("N,dtype", [(1500, "f64"), (4000, "f64"), (5000, "f64"), (16384, "f64"), (4000, "f32")])
+def test_large_n_device_rng_fast_kernel(ctx, monkeypatch, model, kernel, theta, N, dtype):
+    """N > 1024 with the device generator runs pf_big_kernel (thread-major CDF, unrolled search,
+    two chunks in flight; NP2 = 4096 / 16384, odd chunk counts included).  Same estimator as the
+    general large-N kernel (which is pinned to the reference in REPLAY mode): means of score,
+    log-likelihood and filtered state over independent windows agree within Monte-Carlo error,
+    for the Poyiadjis, Nemeth and filter smoothers."""
+    rs = np.random.RandomState(N)
+    T, B = 12, 48
+    y = rs.normal(size=T)
+    w = rs.uniform(1.0, 3.0, size=T - 3)
+    res = {}
+    for variant in ("big", "mem1024"):
+        if variant == "mem1024":
+            monkeypatch.setenv("PFGRAD_VARIANT", "mem1024")
+        else:
+            monkeypatch.delenv("PFGRAD_VARIANT", raising=False)
+        name = ctx.variant_name(model, kernel, dtype, "device", N)
+        assert name == ("mem1024" if variant == "mem1024" else ("big4096" if N <= 4096 else "big16384"))
+        for smoother, lam in (("nemeth", 1.0), ("nemeth", 0.9), ("filter", 1.0)):
+            probs = [dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype=dtype, rng="device",
+                          N=N, t1=2, tL=T - 1, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w,
+                          theta=theta, seed=7 + (variant == "big"), stream=b) for b in range(B)]
+            outs = ctx.run_batch(probs, want_final=True)
+            rows = []
+            for o in outs:
+                p = np.exp(o["log_weights"] - o["log_weights"].max())
+                rows.append(np.concatenate([o["mean_stat"], [o["loglik"], np.sum(p * o["x_t"][:, 0]) / p.sum()]]))
+            res[(variant, smoother, lam)] = np.array(rows)
+            assert np.all(np.isfinite(res[(variant, smoother, lam)]))
+    for smoother, lam in (("nemeth", 1.0), ("nemeth", 0.9), ("filter", 1.0)):
+        a, b = res[("big", smoother, lam)], res[("mem1024", smoother, lam)]
+        se = np.sqrt(a.var(axis=0) / B + b.var(axis=0) / B) + 1e-6 * (1 + np.abs(b.mean(axis=0)))
+        zs = np.abs(a.mean(axis=0) - b.mean(axis=0)) / se
+        assert np.all(zs < 5.5), (smoother, lam, zs, a.mean(axis=0), b.mean(axis=0))
+    # the same window gives the same answer twice (reproducible streams)
+    monkeypatch.delenv("PFGRAD_VARIANT", raising=False)
+    q = dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype=dtype, rng="device", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=0.0, prior_var=1.5, y=y, theta=theta, seed=3, stream=9)
+    o1, o2 = ctx.run_batch([q])[0], ctx.run_batch([q])[0]
+    assert np.array_equal(o1["mean_stat"], o2["mean_stat"]) and o1["loglik"] == o2["loglik"]

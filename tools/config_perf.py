@@ -48,6 +48,8 @@ if which in ("all", "c4"):
 if which in ("all", "c5"): run("C5 svm T=126 N=10000 S16 B4", "svm", 126, 10000, 1, 16, 4); run("C5 svm T=126 N=10000 S16 B4", "svm", 126, 10000, 512, 16, 4)
 if which in ("all", "f32"):
     run("C2 svm f32", "svm", 1000, 1000, 3072, dtype="f32"); run("C4 svm N=4000 f32", "svm", 1000, 4000, 256, dtype="f32", steps=2)
+if which == "c4mem":
+    run("C4 svm T=1000 N=4000 full", "svm", 1000, 4000, 256, steps=2, variant="mem1024")
 if which == "mid":
     for N in (1500, 2000, 3000):
         for v in ("wg1024x4", "wg1024x4s", "mem1024"):
