@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--model", default="svm", choices=["svm", "garch"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-chain", action="store_true",
+                    help="skip the one-chain-alone latency measurement (profiling runs: keeps every "
+                         "launch of the PF kernel the same size, so rocprofv3's per-kernel average is the launch time)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -170,7 +173,7 @@ def main():
 
     # latency of ONE chain alone on the GPU (the reference's unit: one chain, one step at a time)
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_single_chain:
         one = ChainEnsemble(args.model, y, p0, num_chains=1, N=N_PART, pf="poyiadjis_N", kernel=cfg["kernel"],
                             epsilon=cfg["epsilon"], prior=prior, subsequence_length=cfg["S"],
                             buffer_length=cfg["B"], dtype=args.dtype, seed=7, chain_offset=10 ** 6, device=dev_index)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_probe.sh <tag> "<counters>" [bench args]
 TAG=$1; CTRS=$2; shift 2
-ARGS="${@:---steps 3 --warmup 1 --no-cpu-baseline}"
+ARGS="${@:---steps 3 --warmup 1 --no-cpu-baseline --no-single-chain}"
 OUT=/root/repo/gpurun_out/pmc_${TAG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

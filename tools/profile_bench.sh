@@ -5,7 +5,7 @@
 set -e
 TAG=${1:-r01}
 shift || true
-ARGS="${@:---steps 5 --warmup 1 --no-cpu-baseline}"
+ARGS="${@:---steps 5 --warmup 1 --no-cpu-baseline --no-single-chain}"
 OUT=/root/repo/gpurun_out/prof_${TAG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
