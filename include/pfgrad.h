@@ -190,6 +190,18 @@ int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, i
  * the plain entry point serves NEMETH / FILTER) */
 int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
                                int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+/* Buffered-subsequence sampling for resident chains, on the device: for every descriptor b draw
+ * a window start as SGMCMCSampler._random_subsequence_and_buffers does (sgmcmc_sampler.py:259-288;
+ * 'uniform' style: start ~ U{0..T-S}; strict != 0: start = S * U{0..T/S-1}), keyed by
+ * Philox(seed; chain_offset + b, *step_ctr), and point y / T / t1 / tL / weights at
+ * [start - buffer, start + S + buffer) clipped to the series.  weights_table: [T-S+1][S] row per
+ * start (random_subsequence_and_weights, :1969-2017) or NULL.  With this the whole SGLD step is
+ * three launches and no host work: capturable in a hipGraph.  Asynchronous on `hip_stream`. */
+int pfg_sample_windows_device(pfg_ctx *ctx, int B, pfg_dev_problem *dev_probs, const double *y_dev,
+                              const double *weights_table_dev, int T, int S, int buffer, int strict,
+                              uint64_t seed, uint64_t chain_offset, const uint64_t *step_ctr,
+                              void *hip_stream);
+
 /* bytes of per-problem HBM scratch (pfg_dev_problem.scratch, 256-byte aligned) the large-N
  * kernel needs for (model, dtype, rng, N); 0 when an LDS-resident variant serves this size,
  * -1 when N is above the supported maximum (16384) */

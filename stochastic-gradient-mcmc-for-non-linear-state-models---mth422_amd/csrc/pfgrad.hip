@@ -400,6 +400,30 @@ __global__ void sgld_update_kernel(int model, int B, double *__restrict__ theta,
 
 __global__ void bump_counter_kernel(uint64_t *ctr) { *ctr += 1; }
 
+// window starts for resident chains (see pfg_sample_windows_device)
+__global__ void sample_windows_kernel(int B, pfg_dev_problem *__restrict__ probs, const double *__restrict__ y,
+                                      const double *__restrict__ wtab, int T, int S, int buffer, int strict,
+                                      uint64_t seed, uint64_t chain_offset, const uint64_t *__restrict__ step_ctr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint64_t chain = chain_offset + (uint64_t)b, ctr = step_ctr ? *step_ctr : 0ull;
+    const pfg::u32x4 r = pfg::philox4x32_10({(uint32_t)chain, (uint32_t)(chain >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)},
+                                            (uint32_t)seed ^ 0x57494E44u, (uint32_t)(seed >> 32));   // "WIND"
+    const uint32_t range = strict ? (uint32_t)(T / S) : (uint32_t)(T - S + 1);
+    // 64 random bits times the range, high part: bias < range / 2^64
+    const uint64_t bits = ((uint64_t)r.x << 32) | r.y;
+    const int idx = (int)__umul64hi(bits, (uint64_t)range);
+    const int start = strict ? idx * S : idx;
+    const int left = start - buffer > 0 ? start - buffer : 0;
+    const int right = start + S + buffer < T ? start + S + buffer : T;
+    pfg_dev_problem &P = probs[b];
+    P.y = y + left;
+    P.T = right - left;
+    P.t1 = start - left;
+    P.tL = start + S - left;
+    P.weights = wtab ? wtab + (size_t)start * S : nullptr;
+}
+
 // ---- IMQ kernel Stein discrepancy: all K^2 pairs, row i per workgroup-stride, f64 ----------
 constexpr int KSD_MAX_D = 8;
 __global__ __launch_bounds__(256) void imq_ksd_kernel(int K, int d, const double *__restrict__ x,
@@ -548,6 +572,20 @@ int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, doubl
     hipLaunchKernelGGL(sgld_update_kernel, dim3((B + 127) / 128), dim3(128), 0, st, model, B, theta, outs,
                        *hyper, epsilon, Tscale, seed, chain_offset, (const uint64_t *)step_ctr, momentum, alpha);
     if (step_ctr) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, step_ctr);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+int pfg_sample_windows_device(pfg_ctx *ctx, int B, pfg_dev_problem *dev_probs, const double *y_dev,
+                              const double *weights_table_dev, int T, int S, int buffer, int strict,
+                              uint64_t seed, uint64_t chain_offset, const uint64_t *step_ctr, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (B <= 0) return PFG_OK;
+    if (!dev_probs || !y_dev) return fail(ctx, PFG_ERR_INVALID, "pfg_sample_windows_device: NULL argument");
+    if (S < 1 || S > T || buffer < 0) return fail(ctx, PFG_ERR_INVALID, "need 1 <= S <= T and buffer >= 0");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(sample_windows_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)hip_stream, B,
+                       dev_probs, y_dev, weights_table_dev, T, S, buffer, strict, seed, chain_offset, step_ctr);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
 }

@@ -86,7 +86,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
-           "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd")
+           "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device")
 
 _lib = None
 
@@ -164,6 +164,10 @@ def load_library():
     lib.pfg_sghmc_update_device.restype = C.c_int
     lib.pfg_imq_ksd.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp]
     lib.pfg_imq_ksd.restype = C.c_int
+    lib.pfg_sample_windows_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
+                                              C.c_void_p]
+    lib.pfg_sample_windows_device.restype = C.c_int
     _lib = lib
     return lib
 
@@ -324,6 +328,13 @@ class Context:
         self._check(self.lib.pfg_launch_device(self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype],
                                                RNG[rng], int(n_max), int(B), C.c_void_p(dev_probs_ptr),
                                                C.c_void_p(int(stream_ptr))))
+
+    def sample_windows_device(self, B, dev_probs_ptr, y_ptr, weights_table_ptr, T, S, buffer, strict, seed,
+                              chain_offset=0, step_ctr_ptr=None, stream_ptr=0):
+        self._check(self.lib.pfg_sample_windows_device(
+            self.handle, int(B), C.c_void_p(dev_probs_ptr), C.c_void_p(y_ptr), C.c_void_p(weights_table_ptr or 0),
+            int(T), int(S), int(buffer), int(bool(strict)), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            C.c_uint64(int(chain_offset)), C.c_void_p(step_ctr_ptr or 0), C.c_void_p(int(stream_ptr))))
 
     def sgld_update_device(self, model, B, theta_ptr, outs_ptr, hyper, epsilon, Tscale, seed,
                            chain_offset=0, step_ctr_ptr=None, stream_ptr=0):

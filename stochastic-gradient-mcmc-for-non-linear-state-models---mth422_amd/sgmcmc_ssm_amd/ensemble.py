@@ -70,13 +70,17 @@ class ChainEnsemble(object):
       resampling: 'multinomial' (the reference's) | 'systematic' (extension, parity-unpinned)
       sampler: 'sgld' (sample_sgld + project_parameters) | 'sghmc' (extension: momentum with
                friction `friction` in (0,1]; friction = 1 is SGLD)
+      window_sampling: 'host' (NumPy draws one window start per chain and step, descriptors are
+               re-uploaded) | 'device' (a Philox-keyed kernel rewrites the descriptors in HBM: the
+               step is three launches with no host work, and `run(..., graph_steps=K)` replays K
+               steps per hipGraph launch)
     """
 
     def __init__(self, model, observations, parameters, num_chains=None, N=1000, pf="poyiadjis_N",
                  lambduh=None, kernel=None, epsilon=0.1, prior=None, subsequence_length=-1,
                  buffer_length=-1, dtype="f64", seed=0, chain_offset=0, device=None,
                  forward_message=None, partition_style=None, resampling="multinomial",
-                 sampler="sgld", friction=0.1):
+                 sampler="sgld", friction=0.1, window_sampling="host"):
         if not torch.cuda.is_available():
             raise RuntimeError("ChainEnsemble needs an MI355X (no CPU fallback)")
         Parameters, Prior, Helper = _model_info(model)
@@ -97,6 +101,10 @@ class ChainEnsemble(object):
         if sampler not in ("sgld", "sghmc"):
             raise ValueError("sampler must be 'sgld' or 'sghmc'")
         self.sampler, self.friction = sampler, float(friction)
+        if window_sampling not in ("host", "device"):
+            raise ValueError("window_sampling must be 'host' or 'device'")
+        self.window_sampling = window_sampling
+        self._graphs = {}
 
         y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
         self.T = y.shape[0]
@@ -247,22 +255,84 @@ class ChainEnsemble(object):
                                         self.hyper, self.epsilon, float(self.T), self.seed ^ 0x5DEECE66D,
                                         self.chain_offset, self.step_ctr.data_ptr(), st)
 
+    def launch_windows(self, stream=None):
+        """Device-side window sampling (window_sampling='device'): rewrite y / T / t1 / tL / weights of
+        every descriptor for the step *step_ctr is at.  No-op for full-sequence chains."""
+        if self.S == -1:
+            return
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self.ctx.sample_windows_device(
+            self.C, self.desc_dev.data_ptr(), self.y_dev.data_ptr(),
+            self.weights_dev.data_ptr() if self.weights_dev is not None else 0, self.T, self.S, self.B,
+            (self.partition_style or 'uniform') == 'strict', self.seed ^ 0x2545F4914F6CDD1D, self.chain_offset,
+            self.step_ctr.data_ptr(), st)
+
+    def _enqueue_step(self):
+        if self.window_sampling == "device":
+            self.launch_windows()
+        elif self.steps_done > 0 and self._set_windows():
+            self.desc_dev.copy_(torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)),
+                                non_blocking=True)
+        self.launch_pf()
+        self.launch_update()
+
     def step(self, num_steps=1):
         """num_steps x (sample_sgld + project_parameters) for every chain.  Asynchronous."""
         for _ in range(num_steps):
-            if self.steps_done > 0 and self._set_windows():
-                self.desc_dev.copy_(torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)),
-                                    non_blocking=True)
-            self.launch_pf()
-            self.launch_update()
+            self._enqueue_step()
             self.steps_done += 1
 
-    def run(self, num_steps, thin=1):
+    def _graph(self, K):
+        """A hipGraph of K whole steps (window sampling, particle filter, update -- 3K kernel nodes).
+        Every input that changes between steps (parameters, descriptors, RNG step counter) lives
+        in HBM and is advanced by the kernels themselves, so replaying the graph IS running K
+        more steps; it is bitwise the same computation as K eager steps."""
+        if self.S != -1 and self.window_sampling != "device":
+            raise ValueError("graph capture needs window_sampling='device' (or full-sequence chains): "
+                             "host-side window sampling cannot be replayed")
+        g = self._graphs.get(K)
+        if g is None:
+            # one eager step first (code-object load, LDS-size attributes), undone afterwards so
+            # that building the graph does not advance the chains
+            snap = [t.clone() for t in (self.theta_dev, self.momentum_dev, self.step_ctr, self.desc_dev)]
+            self._enqueue_step()
+            self.synchronize()
+            for t, c in zip((self.theta_dev, self.momentum_dev, self.step_ctr, self.desc_dev), snap):
+                t.copy_(c)
+            self.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(K):
+                    self._enqueue_step()
+            self._graphs[K] = g
+        return g
+
+    def run(self, num_steps, thin=1, graph_steps=0):
         """num_steps steps, keeping every `thin`-th state: returns ndarray [num_steps // thin, C, P].
-        Samples are staged in HBM and copied to the host once at the end."""
+        Samples are staged in HBM and copied to the host once at the end.  graph_steps = K > 0
+        replays a captured hipGraph of K steps per launch (K must divide `thin`); worth it when a
+        step is launch-bound (short buffered windows, few chains)."""
         keep = num_steps // thin
         buf = torch.empty((max(keep, 1), self.C, self.P), dtype=torch.float64, device=self.device)
         k = 0
+        K = int(graph_steps)
+        if K > 0:
+            if thin % K != 0:
+                raise ValueError("graph_steps must divide thin")
+            g = self._graph(K)
+            it = 0
+            while it < num_steps:
+                if num_steps - it >= K:
+                    g.replay()
+                    self.steps_done += K
+                    it += K
+                else:
+                    self.step(1)
+                    it += 1
+                if it % thin == 0 and k < keep:
+                    buf[k].copy_(self.theta_dev[:, :self.P])
+                    k += 1
+            return buf[:keep].cpu().numpy()
         for it in range(1, num_steps + 1):
             self.step(1)
             if it % thin == 0 and k < keep:

@@ -39,10 +39,12 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4s"
     assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
     assert lib.pfg_variant_name(0, 0, 0, 1, 1024) == b"wg256x4s"
-    assert lib.pfg_variant_name(0, 0, 0, 1, 1025) == b"mem1024"       # N > 1024: state in HBM scratch
+    assert lib.pfg_variant_name(0, 0, 0, 0, 1025) == b"mem1024"       # N > 1024: state in HBM scratch
+    assert lib.pfg_variant_name(0, 0, 0, 1, 1025) == b"big4096"       # ... device generator: the fast large-N kernel
+    assert lib.pfg_variant_name(0, 0, 0, 1, 10000) == b"big16384"
     assert lib.pfg_variant_name(1, 1, 0, 1, 1000) == b"wg256x4s"      # GARCH fp64 (n=2, h=4) still LDS-resident
-    assert lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"mem1024"
-    assert lib.pfg_variant_name(0, 0, 0, 1, 10000) == b"mem1024" and lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"none"
+    assert lib.pfg_variant_name(1, 1, 0, 0, 4000) == b"mem1024" and lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"big4096"
+    assert lib.pfg_variant_name(0, 0, 0, 0, 10000) == b"mem1024" and lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"none"
     assert lib.pfg_scratch_bytes(0, 0, 1, 1000) == 0 and lib.pfg_scratch_bytes(0, 0, 1, 20000) == -1
     assert lib.pfg_scratch_bytes(0, 0, 1, 10000) == (10000 * 9 * 8 + 16 + 255) // 256 * 256
 

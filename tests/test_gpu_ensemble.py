@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import pf_oracle as po
-from test_host_logic import default_params, PRIORS
+from test_host_logic import default_params, GEN, PRIORS
 
 pytestmark = pytest.mark.gpu
 
@@ -197,3 +197,48 @@ def test_run_checkpoint_resume_and_sghmc():
     out = s2.run(6, thin=1)
     assert np.all(np.isfinite(out)) and not np.array_equal(out[-1], full[-1])
     assert float(s2.momentum_dev.abs().sum()) > 0.0
+
+
+def test_device_window_sampling_and_graph_replay():
+    """window_sampling='device': a Philox-keyed kernel rewrites the window descriptors in HBM
+    (no host work per step); K steps captured in a hipGraph replay bitwise like K eager steps."""
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.models.garch import generate_garch_data
+    p = default_params("garch")
+    np.random.seed(4)
+    T, S, B, C = 400, 16, 4, 512
+    y = generate_garch_data(T=T, parameters=p)["observations"]
+    kw = dict(num_chains=C, N=256, epsilon=0.01, subsequence_length=S, buffer_length=B, seed=11,
+              window_sampling="device")
+    ens = ChainEnsemble("garch", y, p, **kw)
+    # descriptors after one device-side draw
+    ens.launch_windows()
+    ens.synchronize()
+    d = np.frombuffer(ens.desc_dev.cpu().numpy().tobytes(), dtype=_capi.DEV_PROBLEM_DTYPE)
+    left = (d["y"].astype(np.int64) - ens.y_dev.data_ptr()) // 8
+    start = left + d["t1"]
+    assert np.all((start >= 0) & (start <= T - S)) and np.all(d["tL"] - d["t1"] == S)
+    assert np.all(left == np.maximum(0, start - B)) and np.all(left + d["T"] == np.minimum(T, start + S + B))
+    assert np.all(d["weights"].astype(np.int64) == ens.weights_dev.data_ptr() + start * 8 * S)
+    # starts ~ U{0..T-S}: mean and spread of 512 draws
+    assert abs(start.mean() - (T - S) / 2) < 5 * (T - S) / np.sqrt(12 * C) and len(np.unique(start)) > 200
+    # eager vs graph: same seeds, same trajectory, bit for bit
+    a = ChainEnsemble("garch", y, p, **kw)
+    b = ChainEnsemble("garch", y, p, **kw)
+    sa = a.run(7, thin=1)
+    sb = b.run(7, thin=3, graph_steps=3)                 # 2 replays of 3 steps + 1 eager step
+    assert sb.shape == (2, C, 4) and np.all(np.isfinite(sa))
+    np.testing.assert_array_equal(sb[0], sa[2])
+    np.testing.assert_array_equal(sb[1], sa[5])
+    np.testing.assert_array_equal(b.theta(), sa[6])
+    assert a.steps_done == b.steps_done == 7
+    # a different step draws different windows; the host-sampled ensemble cannot be captured
+    with pytest.raises(ValueError):
+        ChainEnsemble("garch", y, p, **dict(kw, window_sampling="host")).run(4, graph_steps=2)
+    # full-sequence chains need no windows: graph works with the default settings
+    pf_ = default_params("svm")
+    ys = GEN["svm"](T=120, parameters=pf_)["observations"]
+    c = ChainEnsemble("svm", ys, pf_, num_chains=64, N=128, epsilon=0.05, seed=2)
+    e = ChainEnsemble("svm", ys, pf_, num_chains=64, N=128, epsilon=0.05, seed=2)
+    np.testing.assert_array_equal(c.run(4, thin=4, graph_steps=4)[0], e.run(4, thin=4)[0])

@@ -48,6 +48,21 @@ if which in ("all", "c4"):
 if which in ("all", "c5"): run("C5 svm T=126 N=10000 S16 B4", "svm", 126, 10000, 1, 16, 4); run("C5 svm T=126 N=10000 S16 B4", "svm", 126, 10000, 512, 16, 4)
 if which in ("all", "f32"):
     run("C2 svm f32", "svm", 1000, 1000, 3072, dtype="f32"); run("C4 svm N=4000 f32", "svm", 1000, 4000, 256, dtype="f32", steps=2)
+if which == "graph":
+    # launch-bound regime: short buffered windows.  host windows (eager) vs device windows (eager) vs hipGraph replay
+    p, gen = params("garch")
+    np.random.seed(1)
+    y = gen(T=1000, parameters=p)["observations"]
+    for C in (1, 64, 4096):
+        for mode, K in (("host", 0), ("device", 0), ("device", 16), ("device", 64)):
+            ens = ChainEnsemble("garch", y, p, num_chains=C, N=1000, epsilon=1e-3, subsequence_length=16, buffer_length=4,
+                                seed=3, window_sampling=mode)
+            n = 256
+            ens.run(64, thin=64, graph_steps=K); ens.synchronize()
+            t0 = time.perf_counter()
+            ens.run(n, thin=n, graph_steps=K); ens.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            print(f"C3 garch S16 B4 C={C:5d} windows={mode:6s} graph_steps={K:3d}: {dt*1e6:9.1f} us/step  {C/dt:12.0f} steps/s", flush=True)
 if which == "c4mem":
     run("C4 svm T=1000 N=4000 full", "svm", 1000, 4000, 256, steps=2, variant="mem1024")
 if which == "mid":
