@@ -60,7 +60,11 @@ int fail(pfg_ctx *ctx, int code, const std::string &msg) {
 // ---- kernel variants ----------------------------------------------------------------
 // pp = ping-pong LDS state buffers (3 barriers/step); single buffer fits larger N (4 barriers).
 struct Variant { int NT, PPT; bool pp; const char *tag; };
-const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"}, {256, 4, false, "wg256x4s"} };
+const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"}, {256, 4, false, "wg256x4s"},
+                              // latency variant: one particle per thread, 16 waves on one CU; picked for
+                              // small batches (fewer windows than a quarter of the CUs), never by order
+                              {1024, 1, true, "wg1024x1"} };
+constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
@@ -82,7 +86,7 @@ size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
 
 // index into kVariants, or -1 when no LDS-resident variant fits.  PFGRAD_VARIANT=<tag> forces a
 // variant (tuning / tests) when it can hold n_max.
-int pick_variant(int model, int dtype, int rng, int n_max) {
+int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) {
     if (const char *force = std::getenv("PFGRAD_VARIANT")) {
         if (!std::strcmp(force, "mem1024") && n_max <= pfg::MEM_MAX_N) return kVariantMem;
         for (int v = 0; v < kNumVariants; ++v)
@@ -93,6 +97,9 @@ int pick_variant(int model, int dtype, int rng, int n_max) {
     // preference order: fp64 N<=1024 runs best on the single-buffer 256x4 variant at 3
     // workgroups per CU; f32 on ping-pong.  N > 1024 goes to the large-N kernel: 1024-thread
     // register-resident variants spill at the 128-VGPR cap and measured 3-5x slower than it.
+    if (batch <= kLatencyBatch && n_max > 256 && n_max <= 1024 &&
+        lds_bytes(model, dtype, rng, kVariants[kLatencyVariant], n_max) <= kLdsLimit)
+        return kLatencyVariant;
     const int order_f64[] = {0, 2, 1}, order_f32[] = {0, 1, 2};
     const int *order = dtype == PFG_F64 ? order_f64 : order_f32;
     for (int oi = 0; oi < 3; ++oi) {
@@ -129,6 +136,7 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
         case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
         case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
         case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
+        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
     }
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
 }
@@ -307,7 +315,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
             : smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC ? kVariantSystematic
             : smoother == PFG_SMOOTHER_POYIADJIS_N2 ? kVariantN2
             : (force_mem && n_max <= pfg::MEM_MAX_N) ? kVariantMem
-            : pick_variant(model, dtype, rng, n_max);
+            : pick_variant(model, dtype, rng, n_max, B);
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));

@@ -108,6 +108,16 @@ def test_window_cases_f64_large_n_kernel(ctx, golden_window, force_mem_kernel):
     test_window_cases_f64(ctx, golden_window)
 
 
+@pytest.mark.parametrize("variant", ["wg256x4", "wg256x4s", "wg1024x1"])
+def test_reference_cases_on_every_lds_variant(ctx, golden_trace, golden_window, monkeypatch, variant):
+    """Single windows with 256 < N <= 1024 are served by the latency variant (wg1024x1), large
+    batches by the throughput variants; every variant must reproduce the reference fixtures, so
+    each is forced in turn (PFGRAD_VARIANT applies where the variant can hold N)."""
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    test_trace_cases_f64(ctx, golden_trace)
+    test_window_cases_f64(ctx, golden_window)
+
+
 def test_large_n_vs_oracle(ctx):
     """N beyond the LDS-resident variants: GARCH fp64 N=4000 (112 B/particle), SVM N=10000
     (BASELINE config 5 shape), LGSSM N=16384 (maximum), Nemeth and filter smoothers."""
