@@ -197,6 +197,20 @@ def main():
         except Exception:
             traffic = None
 
+    # what actually bounds the LDS-resident kernel: VALU issue (4 cycles per wave64 instruction per
+    # SIMD, 1024 SIMDs at 2.4 GHz), from the committed SQ_INSTS_VALU pass of this workload
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
+    if os.path.exists(vpath):
+        try:
+            rec = json.load(open(vpath)).get("{0}_{1}_C{2}".format(args.model, args.dtype, C))
+            if rec:
+                insts = float(rec["SQ_INSTS_VALU_per_launch"])
+                valu = {"insts_per_launch": insts, "issue_cycles_per_inst": 4, "simds": 1024, "clock_ghz": 2.4,
+                        "issue_frac": insts * 4.0 / (1024 * 2.4e9 * kern_ms * 1e-3)}
+        except Exception:
+            valu = None
+
     if rank == 0:
         total_steps = float(C) * world * args.steps
         line = {
@@ -234,7 +248,9 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "state is LDS-resident by design: measured HBM traffic is far below the algorithmic bytes",
+                "note": "state is LDS-resident by design: measured HBM traffic is far below the algorithmic bytes; "
+                        "the binding resource is VALU issue (see valu_issue)",
+                "valu_issue": valu,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
