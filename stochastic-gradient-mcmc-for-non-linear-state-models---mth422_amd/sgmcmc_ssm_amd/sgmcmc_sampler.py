@@ -395,7 +395,11 @@ class SGMCMCSampler(object):
         kwargs.pop('tqdm', None)
         T_total = self._get_T(**kwargs)
         grad_loglike = self._noisy_grad_loglikelihood(**{k: v for k, v in kwargs.items() if k != 'T'})
-        grad_prior = self.prior.grad_logprior(parameters=self.parameters)
+        # a `parameters=` argument reaches the prior term and the preconditioner only: the
+        # particle filter always runs at self.parameters (sgmcmc_sampler.py:379)
+        at = kwargs.get('parameters', None)
+        at = self.parameters if at is None else at
+        grad_prior = self.prior.grad_logprior(parameters=at)
         grad = {var: grad_prior[var] + grad_loglike[var] for var in grad_prior}
         if preconditioner is None:
             if is_scaled:
@@ -403,7 +407,7 @@ class SGMCMCSampler(object):
                     grad[var] = grad[var] / T_total
         else:
             # sgmcmc_sampler.py:452-457: D(theta) * gradient, scaled by 1/T
-            grad = preconditioner.precondition(grad, parameters=self.parameters,
+            grad = preconditioner.precondition(grad, parameters=at,
                                                scale=(1.0 / T_total if is_scaled else 1.0))
         return grad
 
@@ -486,6 +490,25 @@ class SGMCMCSampler(object):
         if "preconditioner" in kwargs:
             raise ValueError("Use SGRLD instead")
         delta = self.noisy_gradient(**kwargs)
+        white_noise = self._get_sgmcmc_noise(**kwargs)
+        for var in self.parameters.var_dict:
+            self.parameters.var_dict[var] += epsilon * delta[var] + np.sqrt(2.0 * epsilon) * white_noise[var]
+        return self.parameters
+
+    def sample_sgld_cv(self, epsilon, centering_parameters, centering_gradient, **kwargs):
+        """SGLD with control variates (sgmcmc_sampler.py:569-611): gradient = centering_gradient +
+        sub_gradient(parameters) - sub_gradient(centering_parameters) on the SAME windows.  As in
+        the reference, with kind='pf' both particle filters run at self.parameters (only the prior
+        term sees centering_parameters) and each consumes its own random draws."""
+        if "preconditioner" in kwargs:
+            raise ValueError("Use SGRLD instead")
+        buffer_dicts = [self._random_subsequence_and_buffers(
+            buffer_length=kwargs.get('buffer_length', 0),
+            subsequence_length=kwargs.get('subsequence_length', -1),
+            T=self._get_T(**kwargs)) for _ in range(kwargs.get('minibatch_size', 1))]
+        cur = self.noisy_gradient(buffer_dicts=buffer_dicts, **kwargs)
+        cen = self.noisy_gradient(parameters=centering_parameters, buffer_dicts=buffer_dicts, **kwargs)
+        delta = {var: centering_gradient[var] + cur[var] - cen[var] for var in cur}
         white_noise = self._get_sgmcmc_noise(**kwargs)
         for var in self.parameters.var_dict:
             self.parameters.var_dict[var] += epsilon * delta[var] + np.sqrt(2.0 * epsilon) * white_noise[var]

@@ -606,6 +606,20 @@ def make_sgrld_fixtures():
             errs[name] = "ok"
         except Exception as e:
             errs[name] = type(e).__name__
+    # sample_sgld_cv (control variates, sgmcmc_sampler.py:569-611) on particle-filter gradients
+    np.random.seed(12345)
+    ysv = generate_svm_data(T=150, parameters=svm_params())["observations"]
+    out["cv/y"] = ysv.reshape(-1)
+    sm = SVMSampler(n=1, m=1, observations=ysv, parameters=svm_params())
+    center = svm_params(A=0.9, Q=0.6, R=0.4)
+    cgrad = dict(A=np.array([[0.3]]), LQinv_vec=np.array([-0.2]), LRinv_vec=np.array([0.1]))
+    np.random.seed(808)
+    try:
+        sm.sample_sgld_cv(epsilon=0.05, centering_parameters=center, centering_gradient=cgrad, kind="pf",
+                          pf="poyiadjis_N", N=120, subsequence_length=16, buffer_length=4, minibatch_size=2)
+        errs["sample_sgld_cv"] = "ok"
+    except Exception as e:       # the reference passes `parameters` twice to grad_logprior: TypeError
+        errs["sample_sgld_cv"] = type(e).__name__
     out["errors"] = np.array(json.dumps(errs))
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(HERE, "sgrld.npz"), **out)
