@@ -1913,6 +1913,11 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     static_assert(CH2 == 4 || CH2 == 16, "NP2 must be 4096 or 16384");
     static_assert(NW == 16, "the wave-total prefix is one 16-lane DPP row scan");
     constexpr int G = 2;                                            // chunks in flight
+    // NP2 = 4096, f32 state: a thread's (<= 4) log-weights never leave its registers (it is the only
+    // reader and writer of its particles' weights): 8 of the 40 B per particle-step stay out of
+    // memory (measured 8.66 -> 7.53 ms per 256 windows of N = 4000).  In fp64 the 8 extra VGPRs
+    // push the kernel over the 128-VGPR cap of a 1024-thread workgroup (53 spills, 15.5 -> 18.6 ms).
+    constexpr bool LWREG = (CH2 == 4) && sizeof(REAL) == 4;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const pfg_dev_problem &P = probs[blockIdx.x];
@@ -1948,6 +1953,9 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
 
     const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
     LaneRng rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
+    REAL lwr[LWREG ? CH2 : 1];
+#pragma unroll
+    for (int j = 0; j < (LWREG ? CH2 : 1); ++j) lwr[j] = (REAL)(-INFINITY);
 
     // ---- x0 or warm start ---------------------------------------------------------------
     {
@@ -1955,7 +1963,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
         if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
             pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
         const double sd = sqrt(pv);
-        for (int i = tid; i < N; i += NT) {
+#pragma unroll (LWREG ? CH2 : 1)
+        for (int jj = 0; jj < (LWREG ? CH2 : MEM_MAX_CHUNKS); ++jj) {
+            const int i = jj * NT + tid;
+            if (i >= N) break;
             REAL x[NS], s[H], l0 = (REAL)0;
 #pragma unroll
             for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
@@ -1974,7 +1985,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                 mth.normal_pair(rng.next(), rng.next(), a, b);
                 x[0] = (REAL)(P.prior_mean + sd * (double)a);
             }
-            lwg[i] = l0;
+            if (LWREG) lwr[LWREG ? jj : 0] = l0;
+            else lwg[i] = l0;
             alignas(16) REAL rec[REC] = {};
 #pragma unroll
             for (int d = 0; d < NS; ++d) rec[d] = x[d];
@@ -2003,7 +2015,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     for (int t = 0; t <= T; ++t) {
         // ---- (A) max of the log weights (f32-rounded shift, see wave_max) -------------------
         float ml = -INFINITY;
-        for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
+        if (LWREG) {
+#pragma unroll
+            for (int j = 0; j < (LWREG ? CH2 : 1); ++j) ml = fmaxf(ml, (float)lwr[j]);   // slots past N hold -inf
+        } else {
+            for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
+        }
         ml = wave_max(ml);
         if (lane == 0) red_maxf[wave] = ml;
         __syncthreads();                                                        // barrier 1
@@ -2026,7 +2043,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                     const int i = j * NT + tid;
                     const bool v = i < N;
                     const int ii = v ? i : N - 1;
-                    double p = (double)mth.exp((REAL)(lwg[ii] - (REAL)m));
+                    const REAL lwv = LWREG ? lwr[LWREG ? j : 0] : lwg[ii];
+                    double p = (double)mth.exp((REAL)(lwv - (REAL)m));
                     p = v ? p : 0.0;
                     if (needS) {
 #pragma unroll
@@ -2143,8 +2161,14 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                         const REAL sm = (lam * sp[h] + oml * (REAL)S[h]) + av;      // pf.py:175-179 / :78-80
                         sp[h] = is_filter ? av : sm;
                     }
+                    if (LWREG) {
+                        // register slot j0 + g, selected without dynamic indexing (rolled loop)
+                        const REAL keep = v[g] ? lwn : (REAL)(-INFINITY);
+#pragma unroll
+                        for (int q = 0; q < (LWREG ? CH2 : 1); ++q) lwr[q] = (q == j0 + g) ? keep : lwr[q];
+                    }
                     if (v[g]) {
-                        lwg[i[g]] = lwn;
+                        if (!LWREG) lwg[i[g]] = lwn;
 #pragma unroll
                         for (int d = 0; d < NS; ++d) rec[g][d] = xn[d];
 #pragma unroll
@@ -2181,10 +2205,13 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
         P.out[4] = ll; P.out[5] = W; P.out[6] = m; P.out[7] = 1.0;
     }
     if (P.final_x) {
-        for (int i = tid; i < N; i += NT) {
+#pragma unroll (LWREG ? CH2 : 1)
+        for (int jj = 0; jj < (LWREG ? CH2 : MEM_MAX_CHUNKS); ++jj) {
+            const int i = jj * NT + tid;
+            if (i >= N) break;
 #pragma unroll
             for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)i * REC + d];
-            if (P.final_logw) P.final_logw[i] = (double)lwg[i];
+            if (P.final_logw) P.final_logw[i] = (double)(LWREG ? lwr[LWREG ? jj : 0] : lwg[i]);
             if (P.final_stats && !is_filter) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)i * REC + NS + h];
