@@ -148,7 +148,7 @@ __device__ __forceinline__ double u01_32(uint32_t a) { return ((double)a + 0.5) 
 //   lg[j] = {1/c_j, log c_j},  c_j = 1 + (j+0.5)/128    j < 128
 //   sc[j] = {sin, cos}(2 pi (j+0.5)/256)                j < 256
 // ------------------------------------------------------------------------------------
-constexpr int TAB_E2 = 128, TAB_LG = 128, TAB_SC = 256;
+constexpr int TAB_E2 = 128, TAB_LG = 128, TAB_SC = 0;     // no sin/cos table: see Math<double,true>::normal_pair
 constexpr int TAB_DOUBLES_EXP = TAB_E2 + 2 * TAB_LG, TAB_DOUBLES_RNG = 2 * TAB_SC;   // exp+log always; sincos with the device RNG
 
 struct TabF64 {
@@ -221,20 +221,17 @@ template <> struct Math<double, true> {
     __device__ __forceinline__ double exp(double x) const { return exp_tab(x, t.e2); }
     __device__ __forceinline__ double log(double x) const { return log_tab(x, t.lg); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
-    // two independent standard normals from two words (Box-Muller, both branches)
+    // two independent standard normals from two words (Box-Muller, both branches).  The draws
+    // are INPUTS of the filter, like the 32-bit uniforms: they are generated with the f32
+    // transcendental units (v_log / v_sin / v_cos: ~12 issue slots per normal instead of ~25 for
+    // a table-based fp64 evaluation) and widened; all arithmetic on the state stays fp64.
+    // u1 keeps its full exponent range ((a + 0.5) 2^-32: |z| up to 6.7), the angle has 24 bits.
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
-        const double lu = log_tab((double)a + 0.5, t.lg) - 22.18070977791825;   // log((a+.5)/2^32)
-        const double r = sqrt_pos(-2.0 * lu);
-        const double2 sc = t.sc[b >> 24];
-        const double dl = (double)((int)(b & 0x00FFFFFFu) - 0x00800000) * 1.4629180792671596e-09;  // 2pi/2^32
-        const double d2 = dl * dl;
-        double sd = fma(d2, 0.008333333333333333, -0.16666666666666666);
-        sd = fma(sd * d2, dl, dl);
-        double cd = fma(d2, -0.001388888888888889, 0.041666666666666664);
-        cd = fma(cd, d2, -0.5);
-        cd = fma(cd, d2, 1.0);
-        z0 = r * fma(sc.y, cd, -(sc.x * sd));        // r cos(theta)
-        z1 = r * fma(sc.x, cd, sc.y * sd);           // r sin(theta)
+        const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;       // (0, 1]
+        const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0,1): angle / 2pi
+        const float r = sqrtf(-2.0f * __logf(u1));
+        z0 = (double)(r * __builtin_amdgcn_cosf(u2));
+        z1 = (double)(r * __builtin_amdgcn_sinf(u2));
     }
 };
 template <> struct Math<double, false> {
@@ -512,8 +509,10 @@ template <int NT, int PPT> struct RegLayout {
 template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
 __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     constexpr bool PARIS = (MODE == MODE_PARIS || MODE == MODE_N2);   // parents' log-weights in LDS
-    size_t NL = (size_t)(N + WAVE - 1) / WAVE * WAVE;
     constexpr bool FAST = fast_layout(NT, PP);
+    // FAST layouts hold NT*PPT particle slots whatever N is: the array stride is a compile-time
+    // constant and folds into the ds_read / ds_write immediates
+    size_t NL = FAST ? (size_t)NT * PPT : (size_t)(N + WAVE - 1) / WAVE * WAVE;
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
 
     const pfg_dev_problem &P = probs[blockIdx.x];
     const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
-    const int NL = (N + WAVE - 1) / WAVE * WAVE;
+    const int NL = fast_layout(NT, PP) ? NT * PPT : (N + WAVE - 1) / WAVE * WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);

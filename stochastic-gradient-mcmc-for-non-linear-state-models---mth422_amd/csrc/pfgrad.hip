@@ -75,8 +75,8 @@ int theta_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
 
 size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
     size_t rs = dtype == PFG_F64 ? 8 : 4;
-    size_t NL = (size_t)(N + 63) / 64 * 64;
     const bool fast = pfg::fast_layout(v.NT, v.pp);
+    size_t NL = fast ? (size_t)v.NT * v.PPT : (size_t)(N + 63) / 64 * 64;
     size_t NC = fast ? (size_t)v.NT * v.PPT + (size_t)v.NT * v.PPT / 32 : NL;
     size_t red = (size_t)v.PPT * (v.NT / 64) + (v.NT / 64) + (size_t)PFG_MAX_STAT * (v.NT / 64) + 8;
     size_t tab = (fast && dtype == PFG_F64)
