@@ -242,3 +242,32 @@ def test_device_window_sampling_and_graph_replay():
     c = ChainEnsemble("svm", ys, pf_, num_chains=64, N=128, epsilon=0.05, seed=2)
     e = ChainEnsemble("svm", ys, pf_, num_chains=64, N=128, epsilon=0.05, seed=2)
     np.testing.assert_array_equal(c.run(4, thin=4, graph_steps=4)[0], e.run(4, thin=4)[0])
+
+
+@pytest.mark.parametrize("N", [1024, 1000, 4096])
+def test_device_generator_normals_and_uniform_streams(N):
+    """The device generator's Gaussian draws (f32 transcendental units, widened to fp64): a T = 0
+    window returns x0 = prior_mean + sd * z, so z is observable.  1M draws: moments, tails and a
+    Kolmogorov-Smirnov test against N(0,1); distinct streams / seeds give distinct draws."""
+    from scipy import stats
+    from sgmcmc_ssm_amd import _capi
+    ctx = _capi.default_context(0)
+    B = 1 << 20
+    B = B // N
+    probs = [dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="device", N=N,
+                  t1=0, tL=0, lambduh=1.0, prior_mean=0.5, prior_var=4.0, y=np.zeros(0), theta=[0.9, 1.0, 1.0],
+                  seed=99, stream=b) for b in range(B)]
+    outs = ctx.run_batch(probs, want_final=True)
+    z = (np.concatenate([o["x_t"][:, 0] for o in outs]) - 0.5) / 2.0
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 5 * np.sqrt(2.0 / n)
+    assert abs(stats.kurtosis(z)) < 5 * np.sqrt(24.0 / n) and abs(stats.skew(z)) < 5 * np.sqrt(6.0 / n)
+    assert stats.kstest(z, "norm").pvalue > 1e-4
+    tail = np.mean(np.abs(z) > 4.0)
+    assert 2e-5 < tail < 1.5e-4 and np.abs(z).max() < 6.8          # P(|z|>4) = 6.3e-5
+    assert len(np.unique(z)) > 0.99 * n                              # no stream reuse across windows / lanes
+    # reproducible for a given (seed, stream, kernel variant): the same launch again gives the same
+    # draws (a launch of <= 64 windows runs the latency variant, whose lanes own other particles)
+    again = ctx.run_batch(probs[:80], want_final=True)
+    assert np.array_equal(again[0]["x_t"], outs[0]["x_t"]) and np.array_equal(again[79]["x_t"], outs[79]["x_t"])
+    assert not np.array_equal(again[1]["x_t"], outs[0]["x_t"])
