@@ -1,0 +1,73 @@
+// Host-side declarations shared by the translation units of libpfgrad.so: the context, error
+// plumbing, the kernel-variant table and the per-(model, kernel) launch entry the instantiation
+// units (pfg_inst_*.hip) define.  Splitting the ~250 kernel instantiations over five units lets
+// the build compile them in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pfgrad.h"
+
+namespace pfg_host {
+
+inline thread_local std::string g_create_error;
+
+struct Arena {           // growable device buffer
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+}  // namespace pfg_host
+
+struct pfg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    pfg_host::Arena in, out, desc, scratch;
+    std::vector<double> h_in, h_out;
+    std::vector<pfg_dev_problem> h_desc;
+};
+
+namespace pfg_host {
+
+inline int fail(pfg_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PFG_HIP(ctx, call)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PFG_ERR_NOMEM : PFG_ERR_DEVICE, \
+                        std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+constexpr size_t kLdsLimit = 160 * 1024;
+// variant ids below zero: kernels other than the LDS-resident table entries
+constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
+constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
+
+// Launch of every kernel of one (model, proposal kernel): defined (and explicitly instantiated)
+// in pfg_inst_*.hip via pfg_launch.hpp, declared here for the dispatcher in pfgrad.hip.
+template <int MODEL, int KERNEL>
+int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
+              hipStream_t st);
+
+}  // namespace pfg_host

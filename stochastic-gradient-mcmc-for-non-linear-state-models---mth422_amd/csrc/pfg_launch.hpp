@@ -1,0 +1,184 @@
+// Kernel launch templates of libpfgrad.so.  Included ONLY by the instantiation units
+// (pfg_inst_*.hip), each of which instantiates launch_mk for one (model, proposal kernel).
+#pragma once
+#include "pfg_host.hpp"
+#include "pfg_device.hpp"
+
+namespace pfg_host {
+
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
+int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    switch (v) {
+        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
+        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
+        case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
+        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
+    }
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
+}
+
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+int launch_paris_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>(n_max);
+    if (lds > kLdsLimit)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 256) return launch_paris_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
+    if (n_max <= 1024) return launch_paris_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
+    if (n_max > pfg::MEM_MAX_N)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 16384 (N = " + std::to_string(n_max) + ")");
+    // large-N kernel, PaRIS instantiation (state in the HBM scratch; descriptors must carry one)
+    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, true>;
+    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+
+// large-N kernel, device-RNG fast path (thread-major CDF, unrolled search, two chunks in flight)
+template <int MODEL, int KERNEL, typename REAL, int NP2>
+int launch_big_one(pfg_ctx *ctx, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_big_kernel<MODEL, KERNEL, REAL, NP2>;
+    size_t lds = pfg::big_kernel_lds_bytes<REAL>(NP2);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL>
+int launch_big(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 4096) return launch_big_one<MODEL, KERNEL, REAL, 4096>(ctx, B, dp, st);
+    return launch_big_one<MODEL, KERNEL, REAL, 16384>(ctx, B, dp, st);
+}
+
+// O(N^2) Poyiadjis smoother instantiations (ping-pong variants, parents' log-weights in LDS)
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
+int launch_n2_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>(n_max);
+    if (lds > kLdsLimit)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_n2(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max <= 256) return launch_n2_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
+    if (n_max <= 1024) return launch_n2_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
+}
+
+// systematic-resampling instantiation (extension): device RNG, the fp64 / f32 default 256x4 variants
+template <int MODEL, int KERNEL, typename REAL, bool PP>
+int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (n_max > 1024) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling is built for N <= 1024");
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>;
+    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>(n_max);
+    if (lds > kLdsLimit) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling: state does not fit LDS");
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int RNG>
+int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
+    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
+    if (lds > 64 * 1024) {
+        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
+
+template <int MODEL, int KERNEL>
+int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
+              hipStream_t st) {
+    if (v == kVariantSystematic) {
+        if (rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
+        if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
+        return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
+    }
+    if (v == kVariantBig) {
+        if (dtype == PFG_F64) return launch_big<MODEL, KERNEL, double>(ctx, n_max, B, dp, st);
+        return launch_big<MODEL, KERNEL, float>(ctx, n_max, B, dp, st);
+    }
+    if (v == kVariantN2) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_n2<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_n2<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+    }
+    if (v == kVariantParis) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_paris<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_paris<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+    }
+    if (v == kVariantMem) {
+        if (dtype == PFG_F64) {
+            if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+            return launch_mem<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        }
+        if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
+        return launch_mem<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+    }
+    if (dtype == PFG_F64) {
+        if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
+        return launch_v<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
+    }
+    if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
+    return launch_v<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
+}
+
+}  // namespace pfg_host

@@ -1,61 +1,21 @@
 // libpfgrad.so: host side of the C ABI declared in include/pfgrad.h + kernel dispatch.
-// Build: see csrc/build.sh (hipcc --offload-arch=gfx950 -ffp-contract=off -shared -fPIC).
-#include <hip/hip_runtime.h>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "pfgrad.h"
+// The particle-filter kernels are instantiated in pfg_inst_*.hip (one unit per model x proposal
+// kernel, compiled in parallel by sgmcmc_ssm_amd/_build.py); this unit holds the dispatcher, the
+// small update / window / KSD kernels and the extern "C" entry points.
+#include "pfg_host.hpp"
 #include "pfg_device.hpp"
 
-namespace {
+using namespace pfg_host;
 
-thread_local std::string g_create_error;
-
-struct Arena {           // growable device buffer
-    void *ptr = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr; cap = 0;
-        size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipMalloc(&ptr, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
-};
-
-}  // namespace
-
-struct pfg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    Arena in, out, desc, scratch;
-    std::vector<double> h_in, h_out;
-    std::vector<pfg_dev_problem> h_desc;
-};
+namespace pfg_host {
+extern template int launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+}  // namespace pfg_host
 
 namespace {
-
-int fail(pfg_ctx *ctx, int code, const std::string &msg) {
-    if (ctx) ctx->err = msg; else g_create_error = msg;
-    return code;
-}
-
-#define PFG_HIP(ctx, call)                                                            \
-    do {                                                                              \
-        hipError_t e_ = (call);                                                       \
-        if (e_ != hipSuccess)                                                         \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? PFG_ERR_NOMEM : PFG_ERR_DEVICE, \
-                        std::string(#call) + ": " + hipGetErrorString(e_));           \
-    } while (0)
 
 // ---- kernel variants ----------------------------------------------------------------
 // pp = ping-pong LDS state buffers (3 barriers/step); single buffer fits larger N (4 barriers).
@@ -66,8 +26,6 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               {1024, 1, true, "wg1024x1"} };
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr size_t kLdsLimit = 160 * 1024;
-constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
 
 int state_dim(int model) { return model == PFG_MODEL_GARCH ? 2 : 1; }
 int stat_dim(int model) { return model == PFG_MODEL_SVM ? 3 : 4; }
@@ -115,182 +73,6 @@ size_t scratch_bytes(int model, int dtype, int N, bool paris = false) {
     const size_t rs = dtype == PFG_F64 ? 8 : 4, per = 16 / rs;
     const size_t rec = (state_dim(model) + stat_dim(model) + per - 1) / per * per;   // pfg::mem_rec_len
     return (size_t)N * rs * (1 + 2 * rec) + 16 + (paris ? (size_t)N * (2 * rs + 8) + 16 : 0);   // pfg::mem_kernel_scratch_bytes
-}
-
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
-int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    switch (v) {
-        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
-        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
-        case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
-        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
-    }
-    return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
-}
-
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
-int launch_paris_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>(n_max);
-    if (lds > kLdsLimit)
-        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (n_max <= 256) return launch_paris_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
-    if (n_max <= 1024) return launch_paris_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
-    if (n_max > pfg::MEM_MAX_N)
-        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris' is implemented for N <= 16384 (N = " + std::to_string(n_max) + ")");
-    // large-N kernel, PaRIS instantiation (state in the HBM scratch; descriptors must carry one)
-    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, true>;
-    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
-
-// large-N kernel, device-RNG fast path (thread-major CDF, unrolled search, two chunks in flight)
-template <int MODEL, int KERNEL, typename REAL, int NP2>
-int launch_big_one(pfg_ctx *ctx, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_big_kernel<MODEL, KERNEL, REAL, NP2>;
-    size_t lds = pfg::big_kernel_lds_bytes<REAL>(NP2);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-template <int MODEL, int KERNEL, typename REAL>
-int launch_big(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (n_max <= 4096) return launch_big_one<MODEL, KERNEL, REAL, 4096>(ctx, B, dp, st);
-    return launch_big_one<MODEL, KERNEL, REAL, 16384>(ctx, B, dp, st);
-}
-
-// O(N^2) Poyiadjis smoother instantiations (ping-pong variants, parents' log-weights in LDS)
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG>
-int launch_n2_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>(n_max);
-    if (lds > kLdsLimit)
-        return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_n2(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (n_max <= 256) return launch_n2_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
-    if (n_max <= 1024) return launch_n2_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
-    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2' is implemented for N <= 1024 (N = " + std::to_string(n_max) + ")");
-}
-
-// systematic-resampling instantiation (extension): device RNG, the fp64 / f32 default 256x4 variants
-template <int MODEL, int KERNEL, typename REAL, bool PP>
-int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (n_max > 1024) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling is built for N <= 1024");
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>;
-    size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>(n_max);
-    if (lds > kLdsLimit) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling: state does not fit LDS");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
-    size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
-    PFG_HIP(ctx, hipGetLastError());
-    return PFG_OK;
-}
-
-
-template <int MODEL, int KERNEL>
-int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
-              hipStream_t st) {
-    if (v == kVariantSystematic) {
-        if (rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
-        if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
-        return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
-    }
-    if (v == kVariantBig) {
-        if (dtype == PFG_F64) return launch_big<MODEL, KERNEL, double>(ctx, n_max, B, dp, st);
-        return launch_big<MODEL, KERNEL, float>(ctx, n_max, B, dp, st);
-    }
-    if (v == kVariantN2) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_n2<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_n2<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-    }
-    if (v == kVariantParis) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_paris<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_paris<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-    }
-    if (v == kVariantMem) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_mem<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_mem<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-    }
-    if (dtype == PFG_F64) {
-        if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-        return launch_v<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
-    }
-    if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-    return launch_v<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
 }
 
 int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {

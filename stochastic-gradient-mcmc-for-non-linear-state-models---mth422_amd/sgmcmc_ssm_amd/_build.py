@@ -1,7 +1,12 @@
-"""Build libpfgrad.so (HIP, gfx950) in-tree with hipcc.  No GPU is needed to compile."""
+"""Build libpfgrad.so (HIP, gfx950) in-tree with hipcc.  No GPU is needed to compile.
+
+The particle-filter kernels are instantiated in five translation units (one per model x proposal
+kernel, csrc/pfg_inst_*.hip) plus the dispatcher / C ABI unit (csrc/pfgrad.hip); the units are
+compiled to objects in parallel and linked into one shared library."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT_PKG = os.path.dirname(PKG_DIR)
@@ -9,8 +14,11 @@ CSRC = os.path.join(ROOT_PKG, "csrc")
 REPO = os.path.dirname(ROOT_PKG)
 INCLUDE = os.path.join(REPO, "include")
 LIB_PATH = os.path.join(CSRC, "libpfgrad.so")
-SOURCES = ["pfgrad.hip"]
-HEADERS = [os.path.join(CSRC, "pfg_device.hpp"), os.path.join(INCLUDE, "pfgrad.h")]
+SOURCES = ["pfgrad.hip", "pfg_inst_svm_prior.hip", "pfg_inst_garch_prior.hip", "pfg_inst_garch_optimal.hip",
+           "pfg_inst_lgssm_prior.hip", "pfg_inst_lgssm_optimal.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("pfg_device.hpp", "pfg_host.hpp", "pfg_launch.hpp")] + \
+          [os.path.join(INCLUDE, "pfgrad.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC"]
 
 
 def _hipcc():
@@ -28,20 +36,36 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
+def _compile(args):
+    hipcc, src, obj, verbose = args
+    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed on {0}:\n{1}".format(os.path.basename(src), res.stdout))
+    return obj
+
+
+def build_library(force=False, verbose=False, jobs=None):
     """Compile csrc/*.hip -> csrc/libpfgrad.so for gfx950.  -ffp-contract=off keeps the f64
     instantiation on the reference's NumPy operation order (see csrc/pfg_device.hpp)."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17",
-           "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    work = [(hipcc, os.path.join(CSRC, s), os.path.join(objdir, os.path.splitext(s)[0] + ".o"), verbose)
+            for s in SOURCES]
+    jobs = jobs or int(os.environ.get("PFGRAD_BUILD_JOBS", "0")) or min(len(work), os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(_compile, work))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
