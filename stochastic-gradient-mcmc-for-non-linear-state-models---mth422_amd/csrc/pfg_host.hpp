@@ -64,10 +64,9 @@ constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
 constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
 
-// Launch of every kernel of one (model, proposal kernel): defined (and explicitly instantiated)
-// in pfg_inst_*.hip via pfg_launch.hpp, declared here for the dispatcher in pfgrad.hip.
-template <int MODEL, int KERNEL>
-int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
-              hipStream_t st);
+// Launch of every kernel of one (model, proposal kernel, generator): defined (and explicitly
+// instantiated) in pfg_inst_*.hip via pfg_launch.hpp, declared here for the dispatcher in pfgrad.hip.
+template <int MODEL, int KERNEL, int RNG>
+int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st);
 
 }  // namespace pfg_host

@@ -1,0 +1,6 @@
+// Instantiation unit: every particle-filter kernel of (PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE).
+#include "pfg_launch.hpp"
+
+namespace pfg_host {
+template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+}  // namespace pfg_host

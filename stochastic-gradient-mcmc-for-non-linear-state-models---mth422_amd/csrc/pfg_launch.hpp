@@ -137,48 +137,42 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 }
 
 
-template <int MODEL, int KERNEL>
-int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp,
-              hipStream_t st) {
+// every kernel of one (model, proposal kernel, generator): explicitly instantiated in
+// pfg_inst_<model>_<kernel>_<rng>.hip.  The DEVICE-generator units are compiled with
+// -ffp-contract=fast (no operation-order parity to keep there), the REPLAY units with
+// -ffp-contract=off (the reference's NumPy operation order).
+template <int MODEL, int KERNEL, int RNG>
+int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     if (v == kVariantSystematic) {
-        if (rng != PFG_RNG_DEVICE) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
-        if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
-        return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
+        if constexpr (RNG != PFG_RNG_DEVICE) {
+            return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
+        } else {
+            if (dtype == PFG_F64) return launch_systematic<MODEL, KERNEL, double, false>(ctx, n_max, B, dp, st);
+            return launch_systematic<MODEL, KERNEL, float, true>(ctx, n_max, B, dp, st);
+        }
     }
     if (v == kVariantBig) {
-        if (dtype == PFG_F64) return launch_big<MODEL, KERNEL, double>(ctx, n_max, B, dp, st);
-        return launch_big<MODEL, KERNEL, float>(ctx, n_max, B, dp, st);
+        if constexpr (RNG != PFG_RNG_DEVICE) {
+            return fail(ctx, PFG_ERR_UNSUPPORTED, "the large-N fast path needs the DEVICE rng");
+        } else {
+            if (dtype == PFG_F64) return launch_big<MODEL, KERNEL, double>(ctx, n_max, B, dp, st);
+            return launch_big<MODEL, KERNEL, float>(ctx, n_max, B, dp, st);
+        }
     }
     if (v == kVariantN2) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_n2<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_n2<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_n2<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        if (dtype == PFG_F64) return launch_n2<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
+        return launch_n2<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
     }
     if (v == kVariantParis) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_paris<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_paris<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_paris<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        if (dtype == PFG_F64) return launch_paris<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
+        return launch_paris<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
     }
     if (v == kVariantMem) {
-        if (dtype == PFG_F64) {
-            if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-            return launch_mem<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
-        }
-        if (rng == PFG_RNG_REPLAY) return launch_mem<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, n_max, B, dp, st);
-        return launch_mem<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, n_max, B, dp, st);
+        if (dtype == PFG_F64) return launch_mem<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
+        return launch_mem<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
     }
-    if (dtype == PFG_F64) {
-        if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, double, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-        return launch_v<MODEL, KERNEL, double, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
-    }
-    if (rng == PFG_RNG_REPLAY) return launch_v<MODEL, KERNEL, float, PFG_RNG_REPLAY>(ctx, v, n_max, B, dp, st);
-    return launch_v<MODEL, KERNEL, float, PFG_RNG_DEVICE>(ctx, v, n_max, B, dp, st);
+    if (dtype == PFG_F64) return launch_v<MODEL, KERNEL, double, RNG>(ctx, v, n_max, B, dp, st);
+    return launch_v<MODEL, KERNEL, float, RNG>(ctx, v, n_max, B, dp, st);
 }
 
 }  // namespace pfg_host

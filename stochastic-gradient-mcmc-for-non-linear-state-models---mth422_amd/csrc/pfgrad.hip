@@ -8,11 +8,22 @@
 using namespace pfg_host;
 
 namespace pfg_host {
-extern template int launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(pfg_ctx *, int, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+
+template <int MODEL, int KERNEL>
+int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (rng == PFG_RNG_REPLAY) return launch_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, v, n_max, B, dp, st);
+    return launch_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, v, n_max, B, dp, st);
+}
 }  // namespace pfg_host
 
 namespace {

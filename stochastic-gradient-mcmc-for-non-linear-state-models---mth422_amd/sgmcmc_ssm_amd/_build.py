@@ -1,8 +1,8 @@
 """Build libpfgrad.so (HIP, gfx950) in-tree with hipcc.  No GPU is needed to compile.
 
-The particle-filter kernels are instantiated in five translation units (one per model x proposal
-kernel, csrc/pfg_inst_*.hip) plus the dispatcher / C ABI unit (csrc/pfgrad.hip); the units are
-compiled to objects in parallel and linked into one shared library."""
+The particle-filter kernels are instantiated in ten translation units (one per model x proposal
+kernel x generator, csrc/pfg_inst_*.hip) plus the dispatcher / C ABI unit (csrc/pfgrad.hip); the
+units are compiled to objects in parallel and linked into one shared library."""
 import os
 import shutil
 import subprocess
@@ -14,11 +14,17 @@ CSRC = os.path.join(ROOT_PKG, "csrc")
 REPO = os.path.dirname(ROOT_PKG)
 INCLUDE = os.path.join(REPO, "include")
 LIB_PATH = os.path.join(CSRC, "libpfgrad.so")
-SOURCES = ["pfgrad.hip", "pfg_inst_svm_prior.hip", "pfg_inst_garch_prior.hip", "pfg_inst_garch_optimal.hip",
-           "pfg_inst_lgssm_prior.hip", "pfg_inst_lgssm_optimal.hip"]
+_UNITS = ["svm_prior", "garch_prior", "garch_optimal", "lgssm_prior", "lgssm_optimal"]
+SOURCES = ["pfgrad.hip"] + ["pfg_inst_{0}_{1}.hip".format(u, r) for u in _UNITS for r in ("device", "replay")]
 HEADERS = [os.path.join(CSRC, h) for h in ("pfg_device.hpp", "pfg_host.hpp", "pfg_launch.hpp")] + \
           [os.path.join(INCLUDE, "pfgrad.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+
+
+def _contract(src):
+    """REPLAY kernels keep the reference's NumPy operation order (no fused multiply-add unless
+    written as fma()); the device-generator kernels have no such parity to keep and fuse."""
+    return "-ffp-contract=fast" if src.endswith("_device.hip") else "-ffp-contract=off"
 
 
 def _hipcc():
@@ -38,7 +44,7 @@ def is_stale():
 
 def _compile(args):
     hipcc, src, obj, verbose = args
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+    cmd = [hipcc] + FLAGS + [_contract(src), "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
