@@ -358,14 +358,25 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
         REAL x1 = c.iLQinv * z + xpA;
         REAL e = mth.exp(-x1);
         REAL y2 = y * y;
+#ifdef PFG_FAST_ALGEBRA
+        // device-generator units (no operation-order parity to keep): the same expressions with
+        // the wave-uniform factors of the step collected (they are computed once per step)
+        const REAL k0 = c.c0 + c.logLRinv, ke = (-half * y2) * c.Rinv;
+        lw = fma(ke, e, fma(-half, x1, k0));
+#else
         lw = ((c.c0 + ((-half * y2) * e) * c.Rinv) + c.logLRinv) + (-half * x1);
+#endif
         xn[0] = x1;
         if (STAT == PFG_STAT_SCORE) {
             REAL dx = x1 - c.A * xp[0];
             add[2] = (c.Qinv * dx) * xp[0];
             add[1] = c.iLQinv - (dx * dx) * c.LQinv;
+#ifdef PFG_FAST_ALGEBRA
+            add[0] = fma(-(y2 * c.LRinv), e, c.iLRinv);
+#else
             REAL dy2 = y2 * e;                       // y^2 / exp(x')
             add[0] = c.iLRinv - dy2 * c.LRinv;
+#endif
         } else {
             add[0] = x1; add[1] = x1 * x1; add[2] = xp[0] * x1;
         }

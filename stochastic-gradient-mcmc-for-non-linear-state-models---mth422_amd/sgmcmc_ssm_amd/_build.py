@@ -24,7 +24,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 def _contract(src):
     """REPLAY kernels keep the reference's NumPy operation order (no fused multiply-add unless
     written as fma()); the device-generator kernels have no such parity to keep and fuse."""
-    return "-ffp-contract=fast" if src.endswith("_device.hip") else "-ffp-contract=off"
+    return ["-ffp-contract=fast", "-DPFG_FAST_ALGEBRA=1"] if src.endswith("_device.hip") else ["-ffp-contract=off"]
 
 
 def _hipcc():
@@ -44,7 +44,7 @@ def is_stale():
 
 def _compile(args):
     hipcc, src, obj, verbose = args
-    cmd = [hipcc] + FLAGS + [_contract(src), "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+    cmd = [hipcc] + FLAGS + _contract(src) + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
