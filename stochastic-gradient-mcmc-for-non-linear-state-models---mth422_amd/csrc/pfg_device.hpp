@@ -178,6 +178,17 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e
     x = fmax(x, -1000.0);
     const double kd = rint(x * 184.6649652337873);                  // 128/ln2
     const int k = (int)kd;
+#ifdef PFG_FAST_ALGEBRA
+    // device-generator units: one-step reduction and a cubic for expm1 -- relative error < 3e-12
+    // (|r| <= ln2/256: r^4/24 = 2e-12), far below the Monte-Carlo noise these kernels carry, and
+    // 4 instructions shorter; the REPLAY units keep the <= 2 ulp form below
+    const double r = fma(kd, -0.0054152123481245725, x);             // ln2/128
+    const double t = e2[k & (TAB_E2 - 1)];
+    double p = fma(r, 0.16666666666666666, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;
+    return ldexp(fma(t, p, t), k >> 7);
+#else
     double r = fma(kd, -0.00541521234663378, x);                     // ln2/128, 32-bit head
     r = fma(kd, -1.4907929134926466e-12, r);                         //          tail
     const double t = e2[k & (TAB_E2 - 1)];
@@ -187,6 +198,7 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e
     p = p * r;
     p = fma(p, r, r);
     return ldexp(fma(t, p, t), k >> 7);
+#endif
 }
 
 // log(x) for finite x > 0 in the normal range
