@@ -1062,6 +1062,55 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
 #pragma unroll
                     for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NL + ci];
                     const double um = (double)nxt[(size_t)NS * NL + ci];
+                    if constexpr (RNG == PFG_RNG_DEVICE) {
+                        // Device generator: any enumeration of the parents is a valid categorical
+                        // sampler, so enumerate LANE-major (lane's parents lane, lane+64, ...): per-lane
+                        // running sums, ONE wave scan over the lane totals, then the owning lane
+                        // resolves its own <= MAXC entries -- no per-chunk wave reductions (they are
+                        // dependent DPP chains with nothing to overlap: one wave per SIMD here).
+                        // fp64 shifts by the block maximum m of the parents' log-weights (the
+                        // backward ratio is <= 0, so every exponent is <= 0); f32 takes the exact max.
+                        REAL mm = (REAL)m;
+                        REAL lq[MAXC];
+                        float mxf2 = -INFINITY;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            const int q = mI * WAVE + lane;
+                            const int qq = q < N ? q : last;
+                            REAL xq[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                            lq[mI] = (q < N && mI < nchunk) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc)
+                                                            : (REAL)(-INFINITY);
+                            mxf2 = fmaxf(mxf2, (float)lq[mI]);
+                        }
+                        if (sizeof(REAL) == 4) mm = (REAL)wave_max(mxf2);
+                        double evl[MAXC], tl = 0.0;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            evl[mI] = (double)mth.exp((REAL)(lq[mI] - mm));       // exp(-inf) = 0
+                            tl += evl[mI];
+                        }
+                        const double incl = wave_incl_scan(tl);
+                        const double target = um * bcast_lane63(incl);
+                        int Lsel = (int)wave_sum(incl <= target ? 1.0 : 0.0);
+                        Lsel = __builtin_amdgcn_readfirstlane(Lsel < WAVE - 1 ? Lsel : WAVE - 1);
+                        const double loc = target - (incl - tl);                  // this lane's local target
+                        double run = 0.0;
+                        int msel = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            run += evl[mI];
+                            const bool here = !found && run > loc;
+                            msel = here ? mI : msel;
+                            found = found || here;
+                        }
+                        int res = msel * WAVE + lane;
+                        res = __builtin_amdgcn_readlane(res, Lsel);
+                        if (lane == 0) queue[e] = res < last ? res : last;
+                        continue;
+                    }
                     REAL l[MAXC];
                     float mxf = -INFINITY;
 #pragma unroll
