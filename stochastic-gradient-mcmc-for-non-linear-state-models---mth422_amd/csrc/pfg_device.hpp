@@ -560,7 +560,8 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
-           (PARIS ? NL * 8 + NL * 4 : 0);     // PaRIS: parents' log-weights + fallback queue in LDS
+           (PARIS ? NL * 8 + NL * 4 + 3 * NL * 4 : 0);   // PaRIS: parents' log-weights, fallback queue,
+                                                         // two wave-queue arrays, accepted parents
 }
 
 // waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
@@ -993,57 +994,99 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                     for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
                 }
             }
+            // wave-local work queues of pending children (this wave's NT*PPT/NW slots of two [NL]
+            // arrays) and the accepted parent of every child of the current backward draw
+            int *const wq0 = paris_queue + NL + wave * (PPT * WAVE);
+            int *const wq1 = paris_queue + 2 * NL + wave * (PPT * WAVE);
+            int *const Jres = paris_queue + 3 * NL;
+            const unsigned long long ltmask = (1ull << lane) - 1ull;
             for (int j = 0; j < Nt; ++j) {
-                // ---- 2. accept-reject against the filter weights, R rounds per child ----------
-                int J[PPT];
+                // ---- 2. accept-reject against the filter weights, up to R rounds per child ------
+                // Pending children sit compacted in a wave-local queue.  While more than half a
+                // wave is pending each lane tries one candidate for one child per pass; below that
+                // a child gets K = 2^k <= 64/pending CONSECUTIVE rounds in one pass (K lanes, the
+                // first accepting round wins -- exactly the sequential outcome, also on replayed
+                // pools), so the long tail of rounds costs a handful of passes.
+                int *qa = wq0, *qb = wq1;
+                int cnt = 0;
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) J[k] = -1;
-                // rounds outermost, slots innermost: PPT independent search chains in flight
-                for (int r = 0; r < R; ++r) {
-                    bool pend[PPT], anyp = false;
-#pragma unroll
-                    for (int k = 0; k < PPT; ++k) { pend[k] = valid[k] && J[k] < 0; anyp = anyp || pend[k]; }
-                    if (!__any(anyp)) break;
-                    double u1[PPT], u2[PPT];
-                    int I[PPT];
-#pragma unroll
-                    for (int k = 0; k < PPT; ++k) {
-                        if (RNG == PFG_RNG_REPLAY) {
-                            const size_t at = (((size_t)t * Nt + j) * R + r) * N + own[k];
-                            u1[k] = pidx[at]; u2[k] = pacc[at];
-                        } else { u1[k] = u01_32(rng.next()); u2[k] = u01_32(rng.next()); }
-                        I[k] = 0;
-                    }
+                for (int k = 0; k < PPT; ++k) {
+                    const unsigned long long mk = __ballot(valid[k]);
+                    if (valid[k]) qa[cnt + __popcll(mk & ltmask)] = k * NT + tid;
+                    cnt += __popcll(mk);
+                }
+                auto candidate = [&](int child, int round, bool act, int &Iout) {
+                    double u1, u2;
+                    if (RNG == PFG_RNG_REPLAY) {
+                        const size_t at = (((size_t)t * Nt + j) * R + (act ? round : 0)) * N + child;
+                        u1 = pidx[at]; u2 = pacc[at];
+                    } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
+                    int I = 0;
 #pragma unroll
                     for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
                         const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
-                        const int adv = step + (step >> 5);
-#pragma unroll
-                        for (int k = 0; k < PPT; ++k) I[k] += (cdf[I[k] + probe] <= u1[k]) ? adv : 0;
+                        I += (cdf[I + probe] <= u1) ? step + (step >> 5) : 0;
                     }
+                    I -= (I * 993) >> 15;
+                    I = I < last ? I : last;
+                    REAL xI[NS], xc[NS];
 #pragma unroll
-                    for (int k = 0; k < PPT; ++k) {
-                        I[k] -= (I[k] * 993) >> 15;
-                        I[k] = I[k] < last ? I[k] : last;
-                        REAL xI[NS];
-#pragma unroll
-                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NL + I[k]];
-                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn[k]));
-                        if (pend[k] && u2[k] <= thr) J[k] = I[k];
+                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)d * NL + I]; xc[d] = nxt[(size_t)d * NL + child]; }
+                    const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
+                    Iout = I;
+                    return act && u2 <= thr;
+                };
+                int r0 = 0;
+                while (cnt > 0 && r0 < R) {                       // wave-uniform
+                    __builtin_amdgcn_wave_barrier();
+                    int ncnt = 0;
+                    if (cnt > WAVE / 2) {
+                        for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+                            const int e = e0 + lane;
+                            const bool act = e < cnt;
+                            const int child = qa[act ? e : 0];
+                            int I;
+                            const bool acc = candidate(child, r0, act, I);
+                            if (acc) Jres[child] = I;
+                            const bool rej = act && !acc;
+                            const unsigned long long mk = __ballot(rej);
+                            if (rej) qb[ncnt + __popcll(mk & ltmask)] = child;
+                            ncnt += __popcll(mk);
+                        }
+                        r0 += 1;
+                    } else {
+                        int logK = 1;
+                        while ((cnt << (logK + 1)) <= WAVE) ++logK;           // cnt * 2^logK <= 64
+                        const int K = 1 << logK;
+                        const int e = lane >> logK, o = lane & (K - 1);
+                        const bool have = e < cnt;
+                        const bool act = have && (r0 + o) < R;
+                        const int child = qa[have ? e : 0];
+                        int I;
+                        const bool acc = candidate(child, r0 + o, act, I);
+                        const unsigned long long am = __ballot(acc);
+                        const unsigned long long segmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+                        const unsigned long long seg = (am >> (e << logK)) & segmask;
+                        const int first = __ffsll((long long)seg) - 1;       // lowest accepting round
+                        if (acc && o == first) Jres[child] = I;
+                        const bool rej = have && o == 0 && seg == 0ull;
+                        const unsigned long long mk = __ballot(rej);
+                        if (rej) qb[__popcll(mk & ltmask)] = child;
+                        ncnt = __popcll(mk);
+                        r0 += K;
                     }
+                    { int *tq = qa; qa = qb; qb = tq; }
+                    cnt = ncnt;
                 }
-                // ---- 3. children still pending: exact categorical draw, one child at a time, the
-                //         whole workgroup over the parents (max / scan / count, as the CDF build) ----
+                // ---- 3. children still pending: exact categorical draw, one child per wave at a
+                //         time over all parents -------------------------------------------------------
                 if (tid == 0) *qcount = 0;
                 __syncthreads();
-                int myslot[PPT];
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    myslot[k] = -1;
-                    if (valid[k] && J[k] < 0) {
-                        const int i = k * NT + tid;
-                        myslot[k] = atomicAdd(qcount, 1);
-                        queue[myslot[k]] = i;
+                for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+                    const int e = e0 + lane;
+                    if (e < cnt) {
+                        const int i = qa[e];
+                        queue[atomicAdd(qcount, 1)] = i;
                         // the child's fallback uniform rides in its (still unused) statistic slot
                         const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
                                                                   : u01_32(rng.next());
@@ -1108,7 +1151,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                         }
                         int res = msel * WAVE + lane;
                         res = __builtin_amdgcn_readlane(res, Lsel);
-                        if (lane == 0) queue[e] = res < last ? res : last;
+                        if (lane == 0) Jres[ci] = res < last ? res : last;
                         continue;
                     }
                     REAL l[MAXC];
@@ -1148,16 +1191,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                     const double inc = wave_incl_scan(evsel) + before;
                     int cnt = ((msel * WAVE + lane) < N && inc <= target) ? 1 : 0;
                     cnt = msel * WAVE + (int)wave_sum((double)cnt);
-                    if (lane == 0) queue[e] = cnt < last ? cnt : last;      // result replaces the entry
+                    if (lane == 0) Jres[ci] = cnt < last ? cnt : last;
                 }
                 __syncthreads();
-#pragma unroll
-                for (int k = 0; k < PPT; ++k)
-                    if (myslot[k] >= 0) J[k] = queue[myslot[k]];
                 // ---- 4. rewired parent: stats[J] + w_t h(x_J, child) ----------------------------
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const int Jk = J[k] < 0 ? 0 : J[k];
+                    const int Jk = valid[k] ? Jres[k * NT + tid] : 0;
                     REAL xJ[NS], aj[H];
 #pragma unroll
                     for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + Jk];

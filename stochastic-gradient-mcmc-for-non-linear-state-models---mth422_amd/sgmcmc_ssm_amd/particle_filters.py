@@ -141,10 +141,10 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
         # left and draws those exactly (its own cap is 100 log10(N/10) rounds); a fixed number of
         # rounds followed by the exact draw is the device equivalent.  The exact draw costs O(N)
-        # per child, a round only touches waves that still hold a pending child: measured
-        # (tools/paris_perf.py) 32 rounds are best up to N = 2048 (256 windows of N = 1000: 16 ms
-        # vs 55 ms with 16 rounds), 64 beyond (N = 10000: 67 ms vs 133 ms per 24-step window).
-        default_rounds = 32 if int(N) <= 2048 else 64
+        # per child; pending children sit in wave-local queues and the tail of rounds is taken
+        # several rounds per pass, so extra rounds are nearly free: measured (tools/paris_perf.py,
+        # SVM N = 1000) 61 / 47 / 43 / 44 us per timestep with 16 / 32 / 64 / 256 rounds.
+        default_rounds = 64
         paris_kw["max_accept_reject"] = default_rounds if mar is None else max(0, int(mar))
         pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
         if rng == "replay" and pools[2] is None:

@@ -96,7 +96,7 @@ def test_paris_device_rng_statistics(ctx, model):
     pm, pv = (0.0, 10.0) if model == "svm" else (0.0, float(po.garch_prior_x(p.theta())[1][0]))
     probs = [make_problem(model, kernel, "paris", y, p.theta(), N, prior_mean=pm, prior_var=pv, seed=5, stream=b)
              for b in range(B)]
-    assert probs[0]["rng"] == "device" and probs[0]["max_accept_reject"] == 32
+    assert probs[0]["rng"] == "device" and probs[0]["max_accept_reject"] == 64
     outs = ctx.run_batch(probs)
     got = np.array([np.append(o["mean_stat"], o["loglik"]) for o in outs])
     rs = np.random.RandomState(1)
