@@ -1398,7 +1398,7 @@ __host__ __device__ constexpr int mem_rec_len() {
 template <int MODEL, typename REAL>
 __host__ __device__ inline size_t mem_kernel_scratch_bytes(int N, bool paris = false) {
     return (size_t)N * sizeof(REAL) * (1 + 2 * mem_rec_len<MODEL, REAL>()) + 16 +
-           (paris ? (size_t)N * (2 * sizeof(REAL) + 8) + 16 : 0);
+           (paris ? (size_t)N * (2 * sizeof(REAL) + 8) + 16 + 2 * (size_t)((N + MEM_NT - 1) / MEM_NT * MEM_NT) * 4 : 0);
 }
 template <int REC, typename REAL>
 __device__ __forceinline__ void rec_load(REAL *dst, const REAL *src) {
@@ -1468,6 +1468,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     REAL *qum = lwn_g + N;                                           // [N] fallback uniforms
     int *qchild = reinterpret_cast<int *>(qum + N);                  // [N]
     int *qres = qchild + N;                                          // [N]
+    int *wq0 = qres + N;                                             // [nchunk*NT] wave-local queues (ping)
+    int *wq1 = wq0 + (size_t)nchunk * MEM_NT;                        // (pong)
     int *qcount = reinterpret_cast<int *>(red_W + 1);                // LDS
     // predictive: the statistic of the newest step, [lead k][particle]; folded into predv by the
     // NEXT iteration's normalisation (its weights are log_normalize(new_logw), pf.py:72-76)
@@ -1842,41 +1844,88 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 }
                 rec_store<REC, REAL>(nxt + (size_t)ci * REC, rc);
             };
+            const unsigned long long ltmask = (1ull << lane) - 1ull;
             for (int jt = 0; jt < Nt; ++jt) {
                 if (tid == 0) *qcount = 0;
                 __syncthreads();
-                // ---- 2. accept-reject against the filter weights, R rounds per child ------------
+                // ---- 2. accept-reject against the filter weights, up to R rounds per child ------
+                // as pf_reg_kernel's paris_slots: pending children compacted in wave-local queues
+                // (here in the scratch), one candidate per child and pass while more than half a
+                // wave is pending, K = 2^k consecutive rounds per child and pass below that
+                int *qa = wq0 + wave * (nchunk * WAVE), *qb = wq1 + wave * (nchunk * WAVE);
+                int cnt = 0;
                 for (int j = 0; j < nchunk; ++j) {
                     const int i = j * NT + tid;
                     const bool v = i < N;
-                    const int ii = v ? i : N - 1;
-                    REAL xn[NS];
+                    const unsigned long long mk = __ballot(v);
+                    if (v) qa[cnt + __popcll(mk & ltmask)] = i;
+                    cnt += __popcll(mk);
+                }
+                auto candidate = [&](int child, int round, bool act, int &Iout) {
+                    double u1, u2;
+                    if (RNG == PFG_RNG_REPLAY) {
+                        const size_t at = (((size_t)t * Nt + jt) * R + (act ? round : 0)) * N + child;
+                        u1 = pidx[at]; u2 = pacc[at];
+                    } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
+                    const int I = search(u1);
+                    REAL xI[NS], xc[NS];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xn[d] = nxt[(size_t)ii * REC + d];
-                    int J = -1;
-                    for (int r = 0; r < R; ++r) {
-                        const bool pend = v && J < 0;
-                        if (!__any(pend)) break;
-                        double u1, u2;
-                        if (RNG == PFG_RNG_REPLAY) {
-                            const size_t at = (((size_t)t * Nt + jt) * R + r) * N + ii;
-                            u1 = pidx[at]; u2 = pacc[at];
-                        } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
-                        const int I = search(u1);
-                        REAL xI[NS];
-#pragma unroll
-                        for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)I * REC + d];
-                        const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn));
-                        if (pend && u2 <= thr) J = I;
-                    }
-                    if (v) {
-                        if (J >= 0) contribute(i, J);
-                        else {
-                            const int e = atomicAdd(qcount, 1);
-                            qchild[e] = i;
-                            qum[e] = (REAL)((RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + jt) * N + i]
-                                                                     : u01_32(rng.next()));
+                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)I * REC + d]; xc[d] = nxt[(size_t)child * REC + d]; }
+                    const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
+                    Iout = I;
+                    return act && u2 <= thr;
+                };
+                int r0 = 0;
+                while (cnt > 0 && r0 < R) {                       // wave-uniform
+                    __threadfence_block();                        // queue stores visible to the other lanes
+                    int ncnt = 0;
+                    if (cnt > WAVE / 2) {
+                        for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+                            const int e = e0 + lane;
+                            const bool act = e < cnt;
+                            const int child = qa[act ? e : 0];
+                            int I;
+                            const bool acc = candidate(child, r0, act, I);
+                            if (acc) contribute(child, I);
+                            const bool rej = act && !acc;
+                            const unsigned long long mk = __ballot(rej);
+                            if (rej) qb[ncnt + __popcll(mk & ltmask)] = child;
+                            ncnt += __popcll(mk);
                         }
+                        r0 += 1;
+                    } else {
+                        int logK = 1;
+                        while ((cnt << (logK + 1)) <= WAVE) ++logK;           // cnt * 2^logK <= 64
+                        const int K = 1 << logK;
+                        const int e = lane >> logK, o = lane & (K - 1);
+                        const bool have = e < cnt;
+                        const bool act = have && (r0 + o) < R;
+                        const int child = qa[have ? e : 0];
+                        int I;
+                        const bool acc = candidate(child, r0 + o, act, I);
+                        const unsigned long long am = __ballot(acc);
+                        const unsigned long long segmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+                        const unsigned long long seg = (am >> (e << logK)) & segmask;
+                        const int first = __ffsll((long long)seg) - 1;       // lowest accepting round
+                        if (acc && o == first) contribute(child, I);
+                        const bool rej = have && o == 0 && seg == 0ull;
+                        const unsigned long long mk = __ballot(rej);
+                        if (rej) qb[__popcll(mk & ltmask)] = child;
+                        ncnt = __popcll(mk);
+                        r0 += K;
+                    }
+                    { int *tq = qa; qa = qb; qb = tq; }
+                    cnt = ncnt;
+                }
+                __threadfence_block();
+                for (int e0 = 0; e0 < cnt; e0 += WAVE) {          // never accepted: exact draw below
+                    const int e = e0 + lane;
+                    if (e < cnt) {
+                        const int i = qa[e];
+                        const int slot = atomicAdd(qcount, 1);
+                        qchild[slot] = i;
+                        qum[slot] = (REAL)((RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + jt) * N + i]
+                                                                    : u01_32(rng.next()));
                     }
                 }
                 __syncthreads();
@@ -1895,6 +1944,42 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                         for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)q * REC + d];
                         return lwg[q] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc);
                     };
+                    if constexpr (RNG == PFG_RNG_DEVICE) {
+                        // device generator: lane-major enumeration (see paris_slots).  Pass 1: per-lane
+                        // sums of the lane's own parents lane, lane+64, ...; one wave scan picks the lane;
+                        // pass 2: the wave re-evaluates that lane's <= 256 entries together.
+                        REAL mm = (REAL)m;                           // fp64: block max of the parents' lw
+                        if (sizeof(REAL) == 4) {
+                            float mxf2 = -INFINITY;
+                            for (int q = lane; q < N; q += WAVE) mxf2 = fmaxf(mxf2, (float)logit(q));
+                            mm = (REAL)wave_max(mxf2);
+                        }
+                        double tl = 0.0;
+                        for (int q = lane; q < N; q += WAVE) tl += (double)mth.exp((REAL)(logit(q) - mm));
+                        const double incl = wave_incl_scan(tl);
+                        const double target = um * bcast_lane63(incl);
+                        int Lsel = (int)wave_sum(incl <= target ? 1.0 : 0.0);
+                        Lsel = __builtin_amdgcn_readfirstlane(Lsel < WAVE - 1 ? Lsel : WAVE - 1);
+                        const double locl = target - (incl - tl);
+                        const double loc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(locl), Lsel),
+                                                            __builtin_amdgcn_readlane(__double2loint(locl), Lsel));
+                        const int nown = (N - Lsel + WAVE - 1) / WAVE;      // entries of lane Lsel (>= 1)
+                        int nle = 0;
+                        double base = 0.0;
+                        for (int sI = 0; sI * WAVE < nown; ++sI) {
+                            const int mI = sI * WAVE + lane;
+                            const bool ok = mI < nown;
+                            const int q = ok ? mI * WAVE + Lsel : Lsel;
+                            const double ev = ok ? (double)mth.exp((REAL)(logit(q) - mm)) : 0.0;
+                            const double inc = wave_incl_scan(ev) + base;
+                            nle += (ok && inc <= loc) ? 1 : 0;
+                            base = bcast_lane63(inc);
+                        }
+                        int msel = (int)wave_sum((double)nle);
+                        msel = msel < nown - 1 ? msel : nown - 1;
+                        if (lane == 0) qres[e] = msel * WAVE + Lsel;
+                        continue;
+                    }
                     float mxf = -INFINITY;
                     for (int q = lane; q < N; q += WAVE) mxf = fmaxf(mxf, (float)logit(q));
                     const REAL mm = (REAL)wave_max(mxf);

@@ -83,7 +83,7 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
 size_t scratch_bytes(int model, int dtype, int N, bool paris = false) {
     const size_t rs = dtype == PFG_F64 ? 8 : 4, per = 16 / rs;
     const size_t rec = (state_dim(model) + stat_dim(model) + per - 1) / per * per;   // pfg::mem_rec_len
-    return (size_t)N * rs * (1 + 2 * rec) + 16 + (paris ? (size_t)N * (2 * rs + 8) + 16 : 0);   // pfg::mem_kernel_scratch_bytes
+    return (size_t)N * rs * (1 + 2 * rec) + 16 + (paris ? (size_t)N * (2 * rs + 8) + 16 + 2 * (size_t)((N + 1023) / 1024 * 1024) * 4 : 0);   // pfg::mem_kernel_scratch_bytes
 }
 
 int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {

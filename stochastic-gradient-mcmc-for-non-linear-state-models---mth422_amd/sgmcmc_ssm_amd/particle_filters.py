@@ -143,8 +143,9 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         # rounds followed by the exact draw is the device equivalent.  The exact draw costs O(N)
         # per child; pending children sit in wave-local queues and the tail of rounds is taken
         # several rounds per pass, so extra rounds are nearly free: measured (tools/paris_perf.py,
-        # SVM N = 1000) 61 / 47 / 43 / 44 us per timestep with 16 / 32 / 64 / 256 rounds.
-        default_rounds = 64
+        # SVM N = 1000) 61 / 47 / 43 / 44 us per timestep with 16 / 32 / 64 / 256 rounds; N = 10000
+        # (exact draw = 10000 parents): 2196 / 659 / 400 us with 16 / 64 / 256 rounds.
+        default_rounds = 64 if int(N) <= 1024 else 256
         paris_kw["max_accept_reject"] = default_rounds if mar is None else max(0, int(mar))
         pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
         if rng == "replay" and pools[2] is None:
