@@ -1,0 +1,273 @@
+// libpfgrad device code: wave primitives (DPP), Philox / lane generators, LDS-table fp64 math.
+// Part of pfg_device.hpp (see there for the overview).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "pfgrad.h"
+
+namespace pfg {
+
+constexpr int WAVE = 64;
+// kernel instantiation modes beyond the plain filter / Nemeth path
+constexpr int MODE_PLAIN = 0, MODE_PARIS = 1, MODE_SYSTEMATIC = 2, MODE_N2 = 3;
+constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
+
+// ------------------------------------------------------------------------------------
+// wave-level primitives (64 lanes) on DPP: row_shr 1,2,4,8 inside 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows (gfx9 cross-lane modes; no LDS traffic).
+// A lane whose DPP source does not exist keeps `old`, the operation's identity.
+// ------------------------------------------------------------------------------------
+// in-row shift with bound_ctrl: lanes without a source read 0 (no preset of the destination)
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr0_f64(double v) {
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ double bcast_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ float bcast_lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// inclusive prefix sum over the wave; lane 63 ends with the wave total
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    v += dpp_shr0_f64<0x111>(v);        // row_shr:1
+    v += dpp_shr0_f64<0x112>(v);        // row_shr:2
+    v += dpp_shr0_f64<0x114>(v);        // row_shr:4
+    v += dpp_shr0_f64<0x118>(v);        // row_shr:8
+    v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) { return bcast_lane63(wave_incl_scan(v)); }
+
+// a value every lane of the wave holds identically: pin it in scalar registers (2 SGPRs instead
+// of 2 VGPRs for as long as it lives)
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#define PFG_MAX_STEP(CTRL, RM) { double o = dpp_f64<CTRL, RM>(v, v); v = o > v ? o : v; }
+    PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)
+    PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
+#undef PFG_MAX_STEP
+    return bcast_lane63(v);
+}
+// The shift m used by log_normalize is reduced in f32 (v_max_f32 takes DPP operands directly:
+// 6 instructions instead of ~50 for f64).  It only has to be within a few ulp(f32) of the true
+// maximum: exp(lw - m) / sum and m + log(W/N) are invariant to it up to rounding.
+__device__ __forceinline__ float wave_max(float v) {
+#define PFG_MAX_STEP(CTRL, RM) { float o = dpp_f32<CTRL, RM>(v, v); v = o > v ? o : v; }
+    PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)
+    PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
+#undef PFG_MAX_STEP
+    return bcast_lane63(v);
+}
+
+// ------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: no state to carry between steps.
+// ------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        u32x4 n;
+        n.x = hi1 ^ c.y ^ k0; n.y = lo1; n.z = hi0 ^ c.w ^ k1; n.w = lo0;
+        c = n; k0 += W0; k1 += W1;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------
+// Device RNG (PFG_RNG_DEVICE): one xoshiro128++ generator per lane (Blackman & Vigna 2019;
+// adds / xors / rotates only -- 32-bit multiplies are quarter-rate on CDNA), its 128-bit state
+// keyed by Philox4x32-10(seed; lane, stream = global chain id, step counter), so streams are
+// reproducible and independent of how chains are spread over GPUs.
+// ------------------------------------------------------------------------------------
+struct LaneRng {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t sum = s0 + s3;
+        const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 11) | (s3 >> 21);
+        return result;
+    }
+};
+
+__device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream, uint64_t step, uint32_t lane) {
+    u32x4 r = philox4x32_10({lane, (uint32_t)step, (uint32_t)stream,
+                             (uint32_t)(stream >> 32) ^ (uint32_t)(step >> 32)},
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    LaneRng g;
+    g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w | 1u;   // never the all-zero state
+    return g;
+}
+
+// uniform in (0,1) with 32 random bits (resampling needs resolution << 1/N only)
+__device__ __forceinline__ double u01_32(uint32_t a) { return ((double)a + 0.5) * (1.0 / 4294967296.0); }
+
+// ------------------------------------------------------------------------------------
+// fp64 elementary functions on small LDS tables.  ocml's exp / log / sincospi cost 42 / 98 / 70
+// VALU instructions each (half of them re-materialising polynomial coefficients); the table
+// forms below need 17 / 20 / 17 and one LDS read, at <= 2 ulp -- well inside the parity
+// tolerance.  Tables are filled once per workgroup with ocml.  Explicit fma(): the file is
+// compiled with -ffp-contract=off.
+//   e2[j] = 2^(j/128)                                   j < 128
+//   lg[j] = {1/c_j, log c_j},  c_j = 1 + (j+0.5)/128    j < 128
+//   sc[j] = {sin, cos}(2 pi (j+0.5)/256)                j < 256
+// ------------------------------------------------------------------------------------
+constexpr int TAB_E2 = 128, TAB_LG = 128, TAB_SC = 0;     // no sin/cos table: see Math<double,true>::normal_pair
+constexpr int TAB_DOUBLES_EXP = TAB_E2 + 2 * TAB_LG, TAB_DOUBLES_RNG = 2 * TAB_SC;   // exp+log always; sincos with the device RNG
+
+struct TabF64 {
+    const double *e2;
+    const double2 *lg;
+    const double2 *sc;
+};
+
+__device__ inline void tab_fill(double *mem, bool with_rng, int tid, int nthreads) {
+    double *lg = mem + TAB_E2, *sc = lg + 2 * TAB_LG;
+    for (int j = tid; j < TAB_E2; j += nthreads) mem[j] = exp2((double)j * (1.0 / 128.0));
+    for (int j = tid; j < TAB_LG; j += nthreads) {
+        const double c = 1.0 + ((double)j + 0.5) * (1.0 / 128.0);
+        lg[2 * j] = 1.0 / c; lg[2 * j + 1] = log(c);
+    }
+    if (with_rng) {
+        for (int j = tid; j < TAB_SC; j += nthreads) {
+            double sn, cs;
+            sincospi(((double)j + 0.5) * (1.0 / 128.0), &sn, &cs);
+            sc[2 * j] = sn; sc[2 * j + 1] = cs;
+        }
+    }
+}
+
+// exp(x), any x (overflow -> inf, underflow -> 0, -inf -> 0)
+__device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e2) {
+    x = fmax(x, -1000.0);
+    const double kd = rint(x * 184.6649652337873);                  // 128/ln2
+    const int k = (int)kd;
+#ifdef PFG_FAST_ALGEBRA
+    // device-generator units: one-step reduction and a cubic for expm1 -- relative error < 3e-12
+    // (|r| <= ln2/256: r^4/24 = 2e-12), far below the Monte-Carlo noise these kernels carry, and
+    // 4 instructions shorter; the REPLAY units keep the <= 2 ulp form below
+    const double r = fma(kd, -0.0054152123481245725, x);             // ln2/128
+    const double t = e2[k & (TAB_E2 - 1)];
+    double p = fma(r, 0.16666666666666666, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;
+    return ldexp(fma(t, p, t), k >> 7);
+#else
+    double r = fma(kd, -0.00541521234663378, x);                     // ln2/128, 32-bit head
+    r = fma(kd, -1.4907929134926466e-12, r);                         //          tail
+    const double t = e2[k & (TAB_E2 - 1)];
+    double p = fma(r, 0.008333333333333333, 0.041666666666666664);   // expm1(r), |r| <= ln2/256
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = p * r;
+    p = fma(p, r, r);
+    return ldexp(fma(t, p, t), k >> 7);
+#endif
+}
+
+// log(x) for finite x > 0 in the normal range
+__device__ __forceinline__ double log_tab(double x, const double2 *__restrict__ lg) {
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const int e = (int)(hi >> 20) - 1023;
+    const double mant = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(x));
+    const double2 t = lg[(hi >> 13) & (TAB_LG - 1)];
+    const double r = fma(mant, t.x, -1.0);                           // |r| <= 2^-8
+    double p = fma(r, 0.2, -0.25);                                   // log1p(r)
+    p = fma(p, r, 0.3333333333333333);
+    p = fma(p, r, -0.5);
+    p = p * r;
+    p = fma(p, r, r);
+    return fma((double)e, 0.6931471805599453, t.y) + p;
+}
+
+// sqrt(x) for finite x > 0 (no special cases): rsq + one coupled Newton step + correction
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
+template <typename REAL, bool TAB> struct Math;
+template <> struct Math<double, true> {
+    TabF64 t;
+    __device__ __forceinline__ double exp(double x) const { return exp_tab(x, t.e2); }
+    __device__ __forceinline__ double log(double x) const { return log_tab(x, t.lg); }
+    __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    // two independent standard normals from two words (Box-Muller, both branches).  The draws
+    // are INPUTS of the filter, like the 32-bit uniforms: they are generated with the f32
+    // transcendental units (v_log / v_sin / v_cos: ~12 issue slots per normal instead of ~25 for
+    // a table-based fp64 evaluation) and widened; all arithmetic on the state stays fp64.
+    // u1 keeps its full exponent range ((a + 0.5) 2^-32: |z| up to 6.7), the angle has 24 bits.
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+        const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;       // (0, 1]
+        const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0,1): angle / 2pi
+        const float r = sqrtf(-2.0f * __logf(u1));
+        z0 = (double)(r * __builtin_amdgcn_cosf(u2));
+        z1 = (double)(r * __builtin_amdgcn_sinf(u2));
+    }
+};
+template <> struct Math<double, false> {
+    TabF64 t;
+    __device__ __forceinline__ double exp(double x) const { return ::exp(x); }
+    __device__ __forceinline__ double log(double x) const { return ::log(x); }
+    __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+        const double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
+        const double r = ::sqrt(-2.0 * ::log(u1));
+        double sn, cs;
+        sincospi((double)b * (1.0 / 2147483648.0), &sn, &cs);
+        z0 = r * cs; z1 = r * sn;
+    }
+};
+template <bool TAB> struct Math<float, TAB> {
+    TabF64 t;
+    __device__ __forceinline__ float exp(float x) const { return __expf(x); }
+    __device__ __forceinline__ float log(float x) const { return __logf(x); }
+    __device__ __forceinline__ float sqrt(float x) const { return sqrtf(x); }
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) const {
+        const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1), 24 bits
+        const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi
+        const float r = sqrtf(-2.0f * __logf(u1));
+        // v_sin_f32 / v_cos_f32 take their argument in revolutions
+        z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
+    }
+};
+
+// bytes of LDS math tables a kernel instantiation carries
+template <typename REAL, int RNG, bool TAB>
+__host__ __device__ constexpr size_t tab_bytes() {
+    return (TAB && sizeof(REAL) == 8) ? (size_t)8 * (TAB_DOUBLES_EXP + (RNG == PFG_RNG_DEVICE ? TAB_DOUBLES_RNG : 0)) : 0;
+}
+
+}  // namespace pfg

@@ -1,0 +1,850 @@
+// libpfgrad device code: pf_reg_kernel, the LDS-resident particle filter (N <= 1024) incl. its
+// PaRIS, systematic-resampling and O(N^2) instantiations.
+#pragma once
+#include "pfg_models.hpp"
+
+namespace pfg {
+
+// ------------------------------------------------------------------------------------
+// LDS-resident kernel: N <= NT*PPT particles; particle i = k*NT + tid belongs to thread tid,
+// slot k.  Only the log-weights live in registers across timesteps; particles and statistics
+// live in LDS as struct-of-arrays over the particle axis (lane i <-> particle i: conflict-free).
+//   LDS: cdf[NL] f64 | buf0 {x[NS][NL], stats[H][NL]} | buf1 (PP only) | reduction scratch
+// PP = ping-pong state buffers: children are written to the other buffer, so no barrier is
+// needed between gathering parents and publishing children (3 barriers per timestep, and a
+// slot's parent state dies as soon as its child is computed).  PP = false keeps ONE buffer
+// (larger N fits in 160 KiB) at the price of a 4th barrier and of holding all gathered
+// parents in registers across it.
+// ------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
+// FAST layout = LDS math tables + sentinel-padded, bank-conflict-free cdf with an unrolled search.
+// Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
+__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 256; }
+
+template <int NT, int PPT> struct RegLayout {
+    static constexpr int NW = NT / WAVE;
+    static constexpr int RED = PPT * NW + NW + PFG_MAX_STAT * NW + 8;  // doubles of scratch
+};
+
+// PP variants: cdf has NT*PPT entries (tail = sentinel 2.0 -> unrolled, clamp-free search) and
+// the fp64 math runs on LDS tables; the single-buffer variant spends its LDS on particles.
+template <int MODEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
+__host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
+    constexpr bool PARIS = (MODE == MODE_PARIS || MODE == MODE_N2);   // parents' log-weights in LDS
+    constexpr bool FAST = fast_layout(NT, PP);
+    // FAST layouts hold NT*PPT particle slots whatever N is: the array stride is a compile-time
+    // constant and folds into the ds_read / ds_write immediates
+    size_t NL = FAST ? (size_t)NT * PPT : (size_t)(N + WAVE - 1) / WAVE * WAVE;
+    size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
+    return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
+           (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
+           (PARIS ? NL * 8 + NL * 4 + 3 * NL * 4 : 0);   // PaRIS: parents' log-weights, fallback queue,
+                                                         // two wave-queue arrays, accepted parents
+}
+
+// waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
+// 256x4 fp64: ping-pong state is 80 KB/workgroup -> 2 workgroups (2 waves/SIMD); the single
+// buffer is 50 KB -> 3, which is worth a few spilled registers (measured +15 %).
+__host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP) {
+    return (NT >= 512 || PPT == 1) ? 4 : ((PP && real == 8) ? 2 : 3);
+}
+__host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP) {
+    return (NT == 256 && PPT == 4 && !PP) ? 3 : 1;
+}
+
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+    constexpr bool PARIS = (MODE == MODE_PARIS);
+    constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
+    constexpr bool N2 = (MODE == MODE_N2);
+    static_assert(!(PARIS || N2) || PP, "PaRIS / O(N^2) need the parents intact while children are built: ping-pong buffers");
+    static_assert(!systematic || RNG == PFG_RNG_DEVICE, "systematic resampling draws its offset on the device");
+    constexpr int NS = ModelDims<MODEL>::NS;
+    constexpr int H = ModelDims<MODEL>::H;
+    constexpr int NW = NT / WAVE;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const pfg_dev_problem &P = probs[blockIdx.x];
+    const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
+    const int NL = fast_layout(NT, PP) ? NT * PPT : (N + WAVE - 1) / WAVE * WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = P.stat;
+    const double lam_d = is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
+    const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
+    const bool needS_every = is_filter || (lam_d != 1.0);
+    const double *__restrict__ const yv = P.y;
+    const double *__restrict__ const wv = P.weights;
+    const double *__restrict__ const uv = P.u;
+    const double *__restrict__ const zv = P.z;
+
+    constexpr bool FAST = fast_layout(NT, PP);
+    constexpr bool TAB = FAST;
+    // Device RNG only: the CDF is built in THREAD-major order (position tid*PPT + k <-> particle
+    // k*NT + tid).  Multinomial resampling does not care how particles are labelled, and in this
+    // order a thread's PPT weights are contiguous: one in-register prefix + ONE wave scan per
+    // thread instead of PPT wave scans.  REPLAY keeps the reference's index order (parity).
+    constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
+    constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : 3));
+    // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
+    // binary search probes at power-of-two strides, which would otherwise all hit one LDS bank
+    // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).
+    const int NC = FAST ? NT * PPT + NT * PPT / 32 : NL;
+    double *cdf = reinterpret_cast<double *>(smem);
+    REAL *buf0 = reinterpret_cast<REAL *>(cdf + NC);
+    const size_t bufsz = (size_t)(NS + H) * NL;
+    REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
+    double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
+    double *red_scan = red;                 // [PPT*NW]
+    double *red_max = red + PPT * NW;       // [NW]
+    float *red_maxf = reinterpret_cast<float *>(red_max);
+    double *red_S = red_max + NW;           // [H*NW]
+    double *red_W0 = red_S + PFG_MAX_STAT * NW;      // [8] spare doubles (systematic-resampling offset)
+    const double invN = 1.0 / (double)N;
+    double *tabmem = red + RegLayout<NT, PPT>::RED;
+    REAL *lwL = reinterpret_cast<REAL *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8);    // [NL], PARIS only
+    int *paris_queue = reinterpret_cast<int *>(tabmem + tab_bytes<REAL, RNG, TAB>() / 8 + NL);   // [NL], PARIS only
+
+    Math<REAL, TAB> mth;
+    mth.t.e2 = tabmem;
+    mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
+    mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
+    if (tab_bytes<REAL, RNG, TAB>() > 0) tab_fill(tabmem, RNG == PFG_RNG_DEVICE, tid, NT);
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (k * NT + tid >= N) cdf[cdf_phys(k * NT + tid)] = 2.0;      // sentinel: never <= u
+    }
+    __syncthreads();
+
+    const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
+    int np2 = 1;
+    while (np2 < N) np2 <<= 1;
+
+    LaneRng rng = {};
+    if (RNG == PFG_RNG_DEVICE)
+        rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
+    // PPT standard normals for this thread's slots (device RNG)
+    auto draw_normals = [&](REAL *zz) {
+#pragma unroll
+        for (int k = 0; k < PPT; k += 2) {
+            REAL a, b;
+            mth.normal_pair(rng.next(), rng.next(), a, b);
+            zz[k] = a;
+            if (k + 1 < PPT) zz[k + 1] = b;
+        }
+    };
+
+    REAL lw[PPT];
+    // ---- x0 (kernels.py:83-100, garch/kernels.py:7-18) or warm start ------------------
+    {
+        double pv = P.prior_var;
+        if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
+            pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
+        const double sd = sqrt(pv);
+        REAL z0[PPT];
+        if (RNG == PFG_RNG_DEVICE) draw_normals(z0);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = k * NT + tid;
+            lw[k] = (REAL)0;
+            if (i < N) {
+                REAL x[NS], s[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) s[h] = (REAL)0;
+                if (P.init_x) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) x[d] = (REAL)P.init_x[(size_t)i * NS + d];
+                    lw[k] = (REAL)P.init_logw[i];
+                    if (P.init_stats && !is_filter) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) s[h] = (REAL)P.init_stats[(size_t)i * H + h];
+                    }
+                } else {
+                    const double z = (RNG == PFG_RNG_REPLAY) ? P.z0[i] : (double)z0[k];
+                    x[0] = (REAL)(P.prior_mean + sd * z);
+                }
+#pragma unroll
+                for (int d = 0; d < NS; ++d) cur[(size_t)d * NL + i] = x[d];
+#pragma unroll
+                for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NL + i] = s[h];
+                if (P.trace_x) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
+                    P.trace_logw[i] = (double)lw[k];
+                    if (P.trace_stats && !is_filter) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) P.trace_stats[(size_t)i * H + h] = (double)s[h];
+                    }
+                }
+            }
+        }
+    }
+
+    double ll = 0.0, wt_prev = 1.0, tie = 1.0;
+    double filt[H], S[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { filt[h] = 0.0; S[h] = 0.0; }
+    double m = 0.0, W = (double)N;
+    // slots beyond N: log-weight -inf (weight exactly 0, never an ancestor); their lanes run the
+    // same straight-line code on clamped indices and only their stores are masked.
+    bool valid[PPT];
+    int own[PPT];                       // own particle index, clamped for reads
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        valid[k] = (k * NT + tid) < N;
+        own[k] = valid[k] ? (k * NT + tid) : (N - 1);
+        if (!valid[k]) lw[k] = -INFINITY;
+    }
+    const int last = N - 1;
+
+    for (int t = 0; t <= T; ++t) {
+        // ---- (A) block max of the current log weights  (log_normalize, pf.py:374-377) ----
+        float ml = (float)lw[0];
+#pragma unroll
+        for (int k = 1; k < PPT; ++k) ml = fmaxf(ml, (float)lw[k]);
+        ml = wave_max(ml);
+        if (lane == 0) red_maxf[wave] = ml;
+        __syncthreads();                                                        // barrier 1
+        {
+            float mm = red_maxf[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
+            m = uniform_f64((double)mm);      // f32-rounded max: a valid shift for log_normalize (see wave_max)
+        }
+        // ---- (B) unnormalised weights, (C) prefix scan + weighted statistic sums --------
+        const bool needS = needS_every || (t == T);
+        double cs[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) cs[k] = (double)mth.exp((REAL)(lw[k] - (REAL)m));   // exp(-inf) = 0
+        if (needS) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double part = 0.0;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) part += (double)cur[(size_t)(NS + h) * NL + own[k]] * cs[k];
+                part = wave_sum(part);
+                if (lane == 0) red_S[h * NW + wave] = part;
+            }
+        }
+        if (BLK) {
+#pragma unroll
+            for (int k = 1; k < PPT; ++k) cs[k] += cs[k - 1];
+            const double inc = wave_incl_scan(cs[PPT - 1]);
+            const double exc = inc - cs[PPT - 1];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cs[k] += exc;
+            if (lane == WAVE - 1) red_scan[wave] = inc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                cs[k] = wave_incl_scan(cs[k]);
+                if (lane == WAVE - 1) red_scan[k * NW + wave] = cs[k];
+            }
+        }
+        if (RNG != PFG_RNG_REPLAY && systematic && tid == 0) red_W0[0] = u01_32(rng.next());
+        // this step's randomness: REPLAY loads are issued here so that their latency overlaps the
+        // barrier; device draws happen right before their use (keeps register pressure down)
+        double uu[PPT];
+        REAL zz[PPT];
+        if (t < T && RNG == PFG_RNG_REPLAY) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                uu[k] = uv[(size_t)t * N + own[k]];
+                zz[k] = (REAL)zv[(size_t)t * N + own[k]];
+            }
+        }
+        __syncthreads();                                                        // barrier 2
+        if (BLK) {
+            // NW wave totals: exclusive prefix by a DPP scan over the first lanes
+            const double tot = (lane < NW) ? red_scan[lane] : 0.0;
+            double inc = tot;
+            inc += dpp_shr0_f64<0x111>(inc);
+            inc += dpp_shr0_f64<0x112>(inc);
+            if (NW > 4) { inc += dpp_shr0_f64<0x114>(inc); inc += dpp_shr0_f64<0x118>(inc); }
+            const double exc = inc - tot;
+            const double off = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), wave),
+                                                __builtin_amdgcn_readlane(__double2loint(exc), wave));
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cs[k] += off;
+            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), NW - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(inc), NW - 1));
+        } else if (PPT * NW <= 16) {
+            // lane j < PPT*NW holds total j; exclusive prefix by a 16-lane DPP scan; each thread
+            // picks its PPT offsets and the grand total with v_readlane (uniform indices)
+            double tot = (lane < PPT * NW) ? red_scan[lane] : 0.0;
+            double inc = tot;
+            inc += dpp_shr0_f64<0x111>(inc);
+            inc += dpp_shr0_f64<0x112>(inc);
+            inc += dpp_shr0_f64<0x114>(inc);
+            inc += dpp_shr0_f64<0x118>(inc);
+            const double exc = inc - tot;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int j = k * NW + wave;
+                cs[k] += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), j),
+                                          __builtin_amdgcn_readlane(__double2loint(exc), j));
+            }
+            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), PPT * NW - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(inc), PPT * NW - 1));
+        } else {
+            double run = 0.0;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                double off = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    off = (w == wave) ? run : off;
+                    run += red_scan[k * NW + w];
+                }
+                cs[k] += off;
+            }
+            W = uniform_f64(run);
+        }
+        const double invW = uniform_f64(1.0 / W);
+        if (needS) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double acc = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc += red_S[h * NW + w];
+                S[h] = uniform_f64(acc * invW);
+            }
+        }
+        // log-likelihood increment of the step that produced these weights
+        // (buffered_smoother.py:124-126): log(mean(exp(logw))) = m + log(W/N).  Wave 0 only.
+        if (wave == 0) {
+            if (t > 0 && (t - 1) >= t1 && (t - 1) < tL) ll = uniform_f64(ll + wt_prev * (m + log(W / (double)N)));
+            if (P.trace_ll && tid == 0) P.trace_ll[t] = ll;
+        }
+        if (is_filter && t > 0) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) filt[h] = uniform_f64(filt[h] + S[h]);
+        }
+        if (t == T) break;
+
+        // ---- (D) normalised CDF to LDS (RandomState.choice: cumsum, /= last) -------------
+        const double y_t = yv[t];
+        const bool inside = (t >= t1) && (t < tL);
+        const double wt = (inside && wv) ? wv[t - t1] : 1.0;
+        const bool use_stat = inside && (stat != PFG_STAT_NONE);
+        const bool plain = !needS_every;                 // not filter and lambda == 1
+        if (BLK) {
+            // all PPT positions: slots beyond N carry weight 0 (flat CDF, never selected)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cdf[cdf_phys(tid * PPT + k)] = cs[k] * invW;
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (valid[k]) {
+                    cdf[FAST ? cdf_phys(k * NT + tid) : k * NT + tid] = cs[k] * invW;
+                    if (PARIS || N2) lwL[k * NT + tid] = lw[k];
+                }
+        }
+        __syncthreads();                                                        // barrier 3
+
+        // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
+        // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
+        if (RNG != PFG_RNG_REPLAY) {
+            if (systematic) {
+                // extension: one uniform per timestep (drawn by thread 0 before barrier 2)
+                const double u0 = red_W0[0];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) uu[k] = ((double)(k * NT + tid) + u0) * invN;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
+            }
+        }
+        int anc[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) anc[k] = 0;
+        if (FAST) {
+            // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
+            // fold into the ds_read immediates; logical index recovered once at the end
+#pragma unroll
+            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                const int adv = step + (step >> 5);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + probe] <= uu[k]) ? adv : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 8192)
+            if (BLK) {
+                // CDF position -> particle index
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) anc[k] = (anc[k] & (PPT - 1)) * NT + (anc[k] >> LOG_PPT);
+            }
+        } else {
+            for (int step = np2 >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    int idx = anc[k] + step - 1;
+                    idx = idx < last ? idx : last;
+                    anc[k] += (cdf[idx] <= uu[k]) ? step : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) anc[k] = anc[k] < last ? anc[k] : last;
+        if (RNG == PFG_RNG_REPLAY) {
+            // near-tie margin: how close u came to flipping an ancestor index
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const double hi = cdf[FAST ? cdf_phys(anc[k]) : anc[k]] - uu[k];
+                const double lo = anc[k] > 0 ? uu[k] - cdf[FAST ? cdf_phys(anc[k] - 1) : anc[k] - 1] : 1.0;
+                const double mg = hi < lo ? hi : lo;
+                tie = (valid[k] && mg < tie) ? mg : tie;
+            }
+        }
+        // ---- (F) gather parents, (G) propose / weight / statistic, (H) publish children ---
+        auto slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            REAL xp[PPT][NS], sp[PPT][H];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[k][d] = cur[(size_t)d * NL + anc[k]];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
+            }
+            if (!PP) __syncthreads();                                           // barrier 4 (single buffer)
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                REAL xn[NS], add[H], lwn;
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
+                lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
+                if (plain) {
+                    // Poyiadjis O(N), lambda = 1: 1*s[a] + 0*S + w_t h = s[a] + w_t h exactly
+                    if (use_stat) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) sp[k][h] = sp[k][h] + add[h] * (REAL)wt;
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
+                        // pf.py:175-179 / :78-80
+                        const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
+                        sp[k][h] = is_filter ? a : sm;
+                    }
+                }
+                if (valid[k]) {
+                    const int i = k * NT + tid;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sp[k][h];
+                }
+            }
+        };
+        // PaRIS (pf.py:183-341): children are proposed from the filter's ancestors as above, then
+        // every child draws Ntilde parents from the backward kernel  w_k q(child | x_k)  by
+        // accept-reject against the filter weights (exact categorical fallback after
+        // max_accept_reject rounds) and averages  stats[J] + w_t h(x_J, child)  over them.
+        auto paris_slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            const int Nt = P.Ntilde, R = P.max_accept_reject;
+            const double *__restrict__ const pidx = P.paris_idx_u;
+            const double *__restrict__ const pacc = P.paris_acc_u;
+            const double *__restrict__ const pman = P.paris_man_u;
+            int *queue = paris_queue;                               // [<= N] children left to the fallback
+            int *qcount = reinterpret_cast<int *>(red_max) + NW;    // behind the NW floats of red_maxf
+            // ---- 1. propose every child from its filter ancestor and publish x' -------------
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+            REAL xn[PPT][NS], lwn[PPT], aux[PPT], sacc[PPT][H];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                REAL xp[NS], add[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
+                aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) sacc[k][h] = (REAL)0;
+                if (valid[k]) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                }
+            }
+            // wave-local work queues of pending children (this wave's NT*PPT/NW slots of two [NL]
+            // arrays) and the accepted parent of every child of the current backward draw
+            int *const wq0 = paris_queue + NL + wave * (PPT * WAVE);
+            int *const wq1 = paris_queue + 2 * NL + wave * (PPT * WAVE);
+            int *const Jres = paris_queue + 3 * NL;
+            const unsigned long long ltmask = (1ull << lane) - 1ull;
+            for (int j = 0; j < Nt; ++j) {
+                // ---- 2. accept-reject against the filter weights, up to R rounds per child ------
+                // Pending children sit compacted in a wave-local queue.  While more than half a
+                // wave is pending each lane tries one candidate for one child per pass; below that
+                // a child gets K = 2^k <= 64/pending CONSECUTIVE rounds in one pass (K lanes, the
+                // first accepting round wins -- exactly the sequential outcome, also on replayed
+                // pools), so the long tail of rounds costs a handful of passes.
+                int *qa = wq0, *qb = wq1;
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const unsigned long long mk = __ballot(valid[k]);
+                    if (valid[k]) qa[cnt + __popcll(mk & ltmask)] = k * NT + tid;
+                    cnt += __popcll(mk);
+                }
+                auto candidate = [&](int child, int round, bool act, int &Iout) {
+                    double u1, u2;
+                    if (RNG == PFG_RNG_REPLAY) {
+                        const size_t at = (((size_t)t * Nt + j) * R + (act ? round : 0)) * N + child;
+                        u1 = pidx[at]; u2 = pacc[at];
+                    } else { u1 = u01_32(rng.next()); u2 = u01_32(rng.next()); }
+                    int I = 0;
+#pragma unroll
+                    for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                        const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                        I += (cdf[I + probe] <= u1) ? step + (step >> 5) : 0;
+                    }
+                    I -= (I * 993) >> 15;
+                    I = I < last ? I : last;
+                    REAL xI[NS], xc[NS];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)d * NL + I]; xc[d] = nxt[(size_t)d * NL + child]; }
+                    const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
+                    Iout = I;
+                    return act && u2 <= thr;
+                };
+                int r0 = 0;
+                while (cnt > 0 && r0 < R) {                       // wave-uniform
+                    __builtin_amdgcn_wave_barrier();
+                    int ncnt = 0;
+                    if (cnt > WAVE / 2) {
+                        for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+                            const int e = e0 + lane;
+                            const bool act = e < cnt;
+                            const int child = qa[act ? e : 0];
+                            int I;
+                            const bool acc = candidate(child, r0, act, I);
+                            if (acc) Jres[child] = I;
+                            const bool rej = act && !acc;
+                            const unsigned long long mk = __ballot(rej);
+                            if (rej) qb[ncnt + __popcll(mk & ltmask)] = child;
+                            ncnt += __popcll(mk);
+                        }
+                        r0 += 1;
+                    } else {
+                        int logK = 1;
+                        while ((cnt << (logK + 1)) <= WAVE) ++logK;           // cnt * 2^logK <= 64
+                        const int K = 1 << logK;
+                        const int e = lane >> logK, o = lane & (K - 1);
+                        const bool have = e < cnt;
+                        const bool act = have && (r0 + o) < R;
+                        const int child = qa[have ? e : 0];
+                        int I;
+                        const bool acc = candidate(child, r0 + o, act, I);
+                        const unsigned long long am = __ballot(acc);
+                        const unsigned long long segmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+                        const unsigned long long seg = (am >> (e << logK)) & segmask;
+                        const int first = __ffsll((long long)seg) - 1;       // lowest accepting round
+                        if (acc && o == first) Jres[child] = I;
+                        const bool rej = have && o == 0 && seg == 0ull;
+                        const unsigned long long mk = __ballot(rej);
+                        if (rej) qb[__popcll(mk & ltmask)] = child;
+                        ncnt = __popcll(mk);
+                        r0 += K;
+                    }
+                    { int *tq = qa; qa = qb; qb = tq; }
+                    cnt = ncnt;
+                }
+                // ---- 3. children still pending: exact categorical draw, one child per wave at a
+                //         time over all parents -------------------------------------------------------
+                if (tid == 0) *qcount = 0;
+                __syncthreads();
+                for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+                    const int e = e0 + lane;
+                    if (e < cnt) {
+                        const int i = qa[e];
+                        queue[atomicAdd(qcount, 1)] = i;
+                        // the child's fallback uniform rides in its (still unused) statistic slot
+                        const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
+                                                                  : u01_32(rng.next());
+                        nxt[(size_t)NS * NL + i] = (REAL)um;
+                    }
+                }
+                __syncthreads();
+                const int nq = *qcount;
+                // one pending child per WAVE at a time: lane handles parents lane, lane+64, ...
+                // (wave-local max / total / ordered cumulative count: no workgroup barrier inside)
+                constexpr int MAXC = NT * PPT / WAVE;
+                const int nchunk = (N + WAVE - 1) / WAVE;
+                for (int e = wave; e < nq; e += NW) {
+                    const int ci = queue[e];
+                    REAL xc[NS];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NL + ci];
+                    const double um = (double)nxt[(size_t)NS * NL + ci];
+                    if constexpr (RNG == PFG_RNG_DEVICE) {
+                        // Device generator: any enumeration of the parents is a valid categorical
+                        // sampler, so enumerate LANE-major (lane's parents lane, lane+64, ...): per-lane
+                        // running sums, ONE wave scan over the lane totals, then the owning lane
+                        // resolves its own <= MAXC entries -- no per-chunk wave reductions (they are
+                        // dependent DPP chains with nothing to overlap: one wave per SIMD here).
+                        // fp64 shifts by the block maximum m of the parents' log-weights (the
+                        // backward ratio is <= 0, so every exponent is <= 0); f32 takes the exact max.
+                        REAL mm = (REAL)m;
+                        REAL lq[MAXC];
+                        float mxf2 = -INFINITY;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            const int q = mI * WAVE + lane;
+                            const int qq = q < N ? q : last;
+                            REAL xq[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                            lq[mI] = (q < N && mI < nchunk) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc)
+                                                            : (REAL)(-INFINITY);
+                            mxf2 = fmaxf(mxf2, (float)lq[mI]);
+                        }
+                        if (sizeof(REAL) == 4) mm = (REAL)wave_max(mxf2);
+                        double evl[MAXC], tl = 0.0;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            evl[mI] = (double)mth.exp((REAL)(lq[mI] - mm));       // exp(-inf) = 0
+                            tl += evl[mI];
+                        }
+                        const double incl = wave_incl_scan(tl);
+                        const double target = um * bcast_lane63(incl);
+                        int Lsel = (int)wave_sum(incl <= target ? 1.0 : 0.0);
+                        Lsel = __builtin_amdgcn_readfirstlane(Lsel < WAVE - 1 ? Lsel : WAVE - 1);
+                        const double loc = target - (incl - tl);                  // this lane's local target
+                        double run = 0.0;
+                        int msel = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int mI = 0; mI < MAXC; ++mI) {
+                            run += evl[mI];
+                            const bool here = !found && run > loc;
+                            msel = here ? mI : msel;
+                            found = found || here;
+                        }
+                        int res = msel * WAVE + lane;
+                        res = __builtin_amdgcn_readlane(res, Lsel);
+                        if (lane == 0) Jres[ci] = res < last ? res : last;
+                        continue;
+                    }
+                    REAL l[MAXC];
+                    float mxf = -INFINITY;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        const int q = mI * WAVE + lane;
+                        const int qq = q < N ? q : last;
+                        REAL xq[NS];
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                        l[mI] = (q < N) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc) : (REAL)(-INFINITY);
+                        mxf = fmaxf(mxf, (float)l[mI]);
+                        if (mI + 1 >= nchunk) break;
+                    }
+                    const REAL mm = (REAL)wave_max(mxf);
+                    // chunk m = parents [64m, 64m+64): independent wave sums (pipelined), then the
+                    // chunk holding the target is scanned once -- index order as np.random.choice
+                    double ev[MAXC], csum[MAXC], tot = 0.0;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        ev[mI] = (mI < nchunk) ? (double)mth.exp((REAL)(l[mI] - mm)) : 0.0;
+                        csum[mI] = wave_sum(ev[mI]);
+                        tot += csum[mI];
+                    }
+                    const double target = um * tot;
+                    double before = 0.0, evsel = 0.0, run = 0.0;
+                    int msel = nchunk - 1;
+                    bool found = false;
+#pragma unroll
+                    for (int mI = 0; mI < MAXC; ++mI) {
+                        const bool here = !found && mI < nchunk && (run + csum[mI] > target || mI == nchunk - 1);
+                        if (here) { msel = mI; before = run; found = true; }
+                        evsel = here ? ev[mI] : evsel;
+                        run += csum[mI];
+                    }
+                    const double inc = wave_incl_scan(evsel) + before;
+                    int cnt = ((msel * WAVE + lane) < N && inc <= target) ? 1 : 0;
+                    cnt = msel * WAVE + (int)wave_sum((double)cnt);
+                    if (lane == 0) Jres[ci] = cnt < last ? cnt : last;
+                }
+                __syncthreads();
+                // ---- 4. rewired parent: stats[J] + w_t h(x_J, child) ----------------------------
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int Jk = valid[k] ? Jres[k * NT + tid] : 0;
+                    REAL xJ[NS], aj[H];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + Jk];
+                    additive_stat<MODEL, STAT, REAL>(c, xJ, xn[k], (REAL)y_t, aux[k], aj);
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                        sacc[k][h] += cur[(size_t)(NS + h) * NL + Jk] + a;
+                    }
+                }
+                __syncthreads();                // queue / statistic-slot scratch free for the next j
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
+                if (valid[k]) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = sacc[k][h] / (REAL)Nt;
+                }
+            }
+        };
+        // Poyiadjis O(N^2) (pf.py:84-136): children are proposed from the filter's ancestors, then
+        // every child averages  stats_j + w_t h(x_j, child)  over ALL parents j with the backward
+        // weights  log_normalize(logw_j + log q(child | x_j)).  Every lane walks the parents in the
+        // same order (LDS broadcast reads); two passes: exact per-child maximum, then exp-sums.
+        auto n2_slots = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+            REAL xn[PPT][NS], lwn[PPT], aux[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                REAL xp[NS], add[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
+                aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
+                if (valid[k]) {
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                }
+            }
+            REAL mx[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) mx[k] = (REAL)(-INFINITY);
+#pragma unroll 2
+            for (int j = 0; j < N; ++j) {
+                REAL xj[NS];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+                const REAL lj = lwL[j];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const REAL v = lj + backward_log_ratio<MODEL, REAL>(c, mth, xj, xn[k]);
+                    mx[k] = v > mx[k] ? v : mx[k];
+                }
+            }
+            REAL den[PPT], num[PPT][H];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                den[k] = (REAL)0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) num[k][h] = (REAL)0;
+            }
+#pragma unroll 2
+            for (int j = 0; j < N; ++j) {
+                REAL xj[NS], sj[H];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sj[h] = cur[(size_t)(NS + h) * NL + j];
+                const REAL lj = lwL[j];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const REAL e = mth.exp((lj + backward_log_ratio<MODEL, REAL>(c, mth, xj, xn[k])) - mx[k]);
+                    REAL aj[H];
+                    additive_stat<MODEL, STAT, REAL>(c, xj, xn[k], (REAL)y_t, aux[k], aj);
+                    den[k] += e;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                        num[k][h] += e * (sj[h] + a);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
+                if (valid[k]) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = num[k][h] / den[k];
+                }
+            }
+        };
+        bool did_paris = false;
+        if constexpr (N2) {
+            if (stat == PFG_STAT_SCORE) n2_slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else n2_slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+            did_paris = true;
+        }
+        if constexpr (MODE == MODE_PARIS) {
+            if (P.smoother == PFG_SMOOTHER_PARIS) {
+                if (stat == PFG_STAT_SCORE) paris_slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+                else paris_slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+                did_paris = true;
+            }
+        }
+        if (!did_paris) {
+            if (stat == PFG_STAT_SCORE) slots(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else slots(std::integral_constant<int, PFG_STAT_SUFF>{});
+        }
+        if (P.trace_x) {
+            // own children back from LDS (written by this thread: no barrier needed)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (valid[k]) {
+                    const int i = k * NT + tid;
+                    const size_t row = (size_t)(t + 1) * N + i;
+                    if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = anc[k];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NL + i];
+                    P.trace_logw[row] = (double)lw[k];
+                    if (P.trace_stats && !is_filter) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+                            P.trace_stats[row * H + h] = (double)nxt[(size_t)(NS + h) * NL + i];
+                    }
+                }
+            }
+        }
+        if (PP) { REAL *tmp = cur; cur = nxt; nxt = tmp; }
+        wt_prev = wt;
+    }
+
+    // ---- outputs --------------------------------------------------------------------
+    if (RNG == PFG_RNG_REPLAY && P.out) {
+        tie = -wave_max(-tie);
+        if (lane == 0) red_max[wave] = tie;
+        __syncthreads();
+        tie = red_max[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
+    }
+    if (tid == 0 && P.out) {
+#pragma unroll
+        for (int h = 0; h < PFG_MAX_STAT; ++h) P.out[h] = 0.0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) P.out[h] = is_filter ? filt[h] : S[h];
+        P.out[4] = ll;
+        P.out[5] = W;
+        P.out[6] = m;
+        P.out[7] = tie;
+    }
+    if (P.final_x) {
+        // own entries of the current buffer: written by this thread, no barrier needed
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = k * NT + tid;
+            if (i < N) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * NL + i];
+                if (P.final_logw) P.final_logw[i] = (double)lw[k];
+                if (P.final_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+                        P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * NL + i];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pfg
