@@ -144,3 +144,40 @@ def test_paris_f32_and_filter_stat(ctx):
         assert np.all(np.isfinite(res[dtype])) and res[dtype].shape[1] == 4
     se = np.sqrt(res["f64"].var(axis=0) / 256 + res["f32"].var(axis=0) / 256)
     assert np.all(np.abs(res["f64"].mean(axis=0) - res["f32"].mean(axis=0)) / se < 5.0)
+
+
+def test_paris_randomised_pool_parity(ctx):
+    """Randomised sweep of the accept-reject machinery: tiny and ragged N (single pending child,
+    K = 64 consecutive rounds per pass), round caps that are not multiples of K, Ntilde 1..3, all
+    models / kernels -- device vs oracle on identical pools, bit-level ancestry (rtol 1e-9)."""
+    rs = np.random.RandomState(2024)
+    for trial in range(36):
+        model, kernel = CASES[trial % len(CASES)]
+        N = int(rs.choice([1, 2, 3, 5, 17, 33, 63, 64, 65, 130, 255, 256, 257, 400, 1000]))
+        Ntilde = int(rs.randint(1, 4))
+        R = int(rs.choice([0, 1, 3, 7, 13, 33, 70]))
+        T = int(rs.randint(2, 6))
+        t1 = int(rs.randint(0, T))
+        tL = int(rs.randint(t1 + 1, T + 1))
+        p = default_params(model)
+        y = rs.normal(size=T) * (1.5 if model != "garch" else 0.7)
+        w = rs.uniform(0.5, 3.0, size=tL - t1) if rs.rand() < 0.5 else None
+        z0, u, z = po.draw_streams(rs, N, T)
+        idx_u = rs.random_sample((T, Ntilde, max(R, 1), N))[:, :, :R]
+        acc_u = rs.random_sample((T, Ntilde, max(R, 1), N))[:, :, :R]
+        man_u = rs.random_sample((T, Ntilde, N))
+        stat = "score" if rs.rand() < 0.7 else "suff"
+        ref = po.pf_window(model, p.theta(), y, N, z0, u, z, kernel=kernel, pf="paris", stat=stat, t1=t1, tL=tL,
+                           weights=w, prior_mean=0.1, prior_var=1.7, save_all=True, Ntilde=Ntilde,
+                           max_accept_reject=R, manual_sample_threshold=0,
+                           paris_draws=po.PoolDraws(idx_u, acc_u, man_u))
+        q = dict(model=model, kernel=kernel, smoother="paris", stat=stat, dtype="f64", rng="replay", N=N, t1=t1,
+                 tL=tL, prior_mean=0.1, prior_var=1.7, y=y, weights=w, theta=p.theta(), z0=z0, u=u, z=z,
+                 Ntilde=Ntilde, max_accept_reject=R, paris_idx_u=np.ascontiguousarray(idx_u),
+                 paris_acc_u=np.ascontiguousarray(acc_u), paris_man_u=man_u)
+        o = ctx.run_batch([q], want_trace=True)[0]
+        tag = str((trial, model, kernel, N, Ntilde, R, T, t1, tL, stat))
+        np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        np.testing.assert_allclose(o["all_statistics"], ref["all_statistics"], rtol=RTOL, atol=1e-8, err_msg=tag)
+        np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8, err_msg=tag)
+        assert abs(o["loglik"] - ref["loglikelihood_estimate"]) <= ATOL + RTOL * abs(ref["loglikelihood_estimate"]), tag
