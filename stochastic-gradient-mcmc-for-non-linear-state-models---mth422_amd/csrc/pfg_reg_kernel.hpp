@@ -36,7 +36,9 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     // constant and folds into the ds_read / ds_write immediates
     size_t NL = FAST ? (size_t)NT * PPT : (size_t)(N + WAVE - 1) / WAVE * WAVE;
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
-    return NC * 8 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
+    // device generator (plain smoothers): 32-bit fixed-point CDF, see pf_reg_kernel
+    constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
+    return (NC * (BLK ? 4 : 8) + 15) / 16 * 16 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
            (PARIS ? NL * 8 + NL * 4 + 3 * NL * 4 : 0);   // PaRIS: parents' log-weights, fallback queue,
                                                          // two wave-queue arrays, accepted parents
@@ -92,7 +94,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).
     const int NC = FAST ? NT * PPT + NT * PPT / 32 : NL;
     double *cdf = reinterpret_cast<double *>(smem);
-    REAL *buf0 = reinterpret_cast<REAL *>(cdf + NC);
+    // BLK: the uniforms carry 32 random bits, so the CDF is kept as 32-bit fixed point
+    // (floor(cdf * 2^32)) and searched with the raw generator word: integer compares, half the
+    // LDS bytes per probe, no u32 -> f64 conversion of the uniform.
+    uint32_t *cdfu = reinterpret_cast<uint32_t *>(smem);
+    REAL *buf0 = reinterpret_cast<REAL *>(smem + ((size_t)NC * (BLK ? 4 : 8) + 15) / 16 * 16);
     const size_t bufsz = (size_t)(NS + H) * NL;
     REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
     double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
     mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
     mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
     if (tab_bytes<REAL, RNG, TAB>() > 0) tab_fill(tabmem, RNG == PFG_RNG_DEVICE, tid, NT);
-    if (FAST) {
+    if (FAST && !BLK) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
             if (k * NT + tid >= N) cdf[cdf_phys(k * NT + tid)] = 2.0;      // sentinel: never <= u
@@ -334,8 +340,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         const bool plain = !needS_every;                 // not filter and lambda == 1
         if (BLK) {
             // all PPT positions: slots beyond N carry weight 0 (flat CDF, never selected)
+            {
+                const double fixs = invW * 4294967296.0;
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) cdf[cdf_phys(tid * PPT + k)] = cs[k] * invW;
+                for (int k = 0; k < PPT; ++k)
+                    cdfu[cdf_phys(tid * PPT + k)] = (uint32_t)fmin(cs[k] * fixs, 4294967295.0);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 const double u0 = red_W0[0];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) uu[k] = ((double)(k * NT + tid) + u0) * invN;
-            } else {
+            } else if (!BLK) {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) uu[k] = u01_32(rng.next());
             }
@@ -362,7 +372,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
         int anc[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = 0;
-        if (FAST) {
+        if (BLK) {
+            uint32_t ua[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) ua[k] = rng.next();
+#pragma unroll
+            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                const int adv = step + (step >> 5);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) anc[k] += (cdfu[anc[k] + probe] <= ua[k]) ? adv : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                anc[k] -= (anc[k] * 993) >> 15;                                 // physical -> CDF position
+                anc[k] = (anc[k] & (PPT - 1)) * NT + (anc[k] >> LOG_PPT);       // -> particle index
+            }
+        } else if (FAST) {
             // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
             // fold into the ds_read immediates; logical index recovered once at the end
 #pragma unroll
@@ -373,12 +399,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, 
                 for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + probe] <= uu[k]) ? adv : 0;
             }
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 8192)
-            if (BLK) {
-                // CDF position -> particle index
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) anc[k] = (anc[k] & (PPT - 1)) * NT + (anc[k] >> LOG_PPT);
-            }
+            for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 32768)
         } else {
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
 #pragma unroll
