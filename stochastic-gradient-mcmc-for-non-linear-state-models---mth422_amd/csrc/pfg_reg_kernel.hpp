@@ -19,7 +19,7 @@ namespace pfg {
 __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
 // FAST layout = LDS math tables + sentinel-padded, bank-conflict-free cdf with an unrolled search.
 // Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
-__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 256; }
+__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 256 || NT == 1024; }
 
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;

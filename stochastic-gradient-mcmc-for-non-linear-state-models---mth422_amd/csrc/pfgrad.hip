@@ -34,7 +34,11 @@ struct Variant { int NT, PPT; bool pp; const char *tag; };
 const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4"}, {256, 4, false, "wg256x4s"},
                               // latency variant: one particle per thread, 16 waves on one CU; picked for
                               // small batches (fewer windows than a quarter of the CUs), never by order
-                              {1024, 1, true, "wg1024x1"} };
+                              {1024, 1, true, "wg1024x1"},
+                              // 1024 < N <= 4096 with the device generator when the state fits LDS
+                              // (32-bit CDF): SVM fp64, every model in f32
+                              {1024, 4, false, "wg1024x4s"} };
+constexpr int kLds4096Variant = 4;
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -77,6 +81,9 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
         if (n_max <= kVariants[v].NT * kVariants[v].PPT && lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
             return v;
     }
+    if (rng == PFG_RNG_DEVICE && n_max <= 4096 &&
+        lds_bytes(model, dtype, rng, kVariants[kLds4096Variant], n_max) <= kLdsLimit)
+        return kLds4096Variant;
     if (n_max <= pfg::MEM_MAX_N) return kVariantMem;
     return -1;
 }

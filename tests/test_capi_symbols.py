@@ -40,7 +40,9 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg256x1"
     assert lib.pfg_variant_name(0, 0, 0, 1, 1024) == b"wg256x4s"
     assert lib.pfg_variant_name(0, 0, 0, 0, 1025) == b"mem1024"       # N > 1024: state in HBM scratch
-    assert lib.pfg_variant_name(0, 0, 0, 1, 1025) == b"big4096"       # ... device generator: the fast large-N kernel
+    assert lib.pfg_variant_name(0, 0, 0, 1, 1025) == b"wg1024x4s"     # ... device generator, SVM fp64: still fits LDS (32-bit CDF)
+    assert lib.pfg_variant_name(2, 1, 0, 1, 4096) == b"big4096"       # LGSSM fp64 (5 arrays) does not: fast large-N kernel
+    assert lib.pfg_variant_name(2, 1, 1, 1, 4096) == b"wg1024x4s"     # ... in f32 it does
     assert lib.pfg_variant_name(0, 0, 0, 1, 10000) == b"big16384"
     assert lib.pfg_variant_name(1, 1, 0, 1, 1000) == b"wg256x4s"      # GARCH fp64 (n=2, h=4) still LDS-resident
     assert lib.pfg_variant_name(1, 1, 0, 0, 4000) == b"mem1024" and lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"big4096"
