@@ -47,15 +47,24 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
 // waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
 // 256x4 fp64: ping-pong state is 80 KB/workgroup -> 2 workgroups (2 waves/SIMD); the single
 // buffer is 50 KB -> 3, which is worth a few spilled registers (measured +15 %).
-__host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP) {
-    return (NT >= 512 || PPT == 1) ? 4 : ((PP && real == 8) ? 2 : 3);
+__host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
+    return (NT >= 512 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
 }
-__host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP) {
-    return (NT == 256 && PPT == 4 && !PP) ? 3 : 1;
+__host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
+    return dev4 ? 4 : ((NT == 256 && PPT == 4 && !PP) ? 3 : 1);
+}
+// The device-generator SVM single-buffer workgroup needs 39.5 KB of LDS with the 32-bit CDF:
+// FOUR workgroups fit a CU if the kernel stays within 128 VGPRs (34 spilled registers; measured
+// +3.6 % workgroups per ms over occupancy 3).  -DPFG_OCC4=0 restores occupancy 3.
+#ifndef PFG_OCC4
+#define PFG_OCC4 1
+#endif
+__host__ __device__ constexpr bool occ_dev4(int MODEL, int NT, int PPT, int RNG, bool PP, int MODE) {
+    return PFG_OCC4 && MODEL == PFG_MODEL_SVM && NT == 256 && PPT == 4 && !PP && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN;
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP), occ_max(NT, PPT, sizeof(REAL), PP)))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE)), occ_max(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE))))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr bool PARIS = (MODE == MODE_PARIS);
     constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
     constexpr bool N2 = (MODE == MODE_N2);
