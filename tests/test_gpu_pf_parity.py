@@ -313,3 +313,44 @@ def test_large_n_device_rng_fast_kernel(ctx, monkeypatch, model, kernel, theta, 
              lambduh=1.0, prior_mean=0.0, prior_var=1.5, y=y, theta=theta, seed=3, stream=9)
     o1, o2 = ctx.run_batch([q])[0], ctx.run_batch([q])[0]
     assert np.array_equal(o1["mean_stat"], o2["mean_stat"]) and o1["loglik"] == o2["loglik"]
+
+
+@pytest.mark.parametrize("variant", ["auto", "wg256x4", "wg256x4s", "wg1024x1", "mem1024"])
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "prior"), ("garch", "optimal"),
+                                          ("lgssm", "prior"), ("lgssm", "optimal")])
+def test_randomised_windows_every_variant(ctx, monkeypatch, model, kernel, variant):
+    """Randomised ragged batches (N, T, window, weights, lambda, smoother, statistic drawn at
+    random) for every model / proposal on every kernel variant, REPLAY fp64 vs the oracle."""
+    if variant == "auto":
+        monkeypatch.delenv("PFGRAD_VARIANT", raising=False)
+    else:
+        monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    rs = np.random.RandomState(sum(map(ord, model + kernel + variant)))
+    from test_host_logic import default_params
+    theta = default_params(model).theta()
+    probs, refs = [], []
+    for b in range(10):
+        N = int(rs.choice([1, 3, 64, 65, 200, 257, 999, 1000, 1024]))
+        T = int(rs.choice([0, 1, 3, 9, 20]))
+        t1 = int(rs.randint(0, T + 1))
+        tL = int(rs.randint(t1, T + 1))
+        y = rs.normal(size=T) * (1.5 if model != "garch" else 0.6)
+        w = rs.uniform(0.5, 10.0, size=tL - t1) if rs.rand() < 0.5 else None
+        z0, u, z = po.draw_streams(rs, N, T)
+        smoother, lam = [("nemeth", 1.0), ("nemeth", 0.9), ("filter", 1.0)][int(rs.randint(3))]
+        stat = "score" if rs.rand() < 0.7 else "suff"
+        probs.append(dict(model=model, kernel=kernel, smoother=smoother, stat=stat, dtype="f64", rng="replay", N=N,
+                          t1=t1, tL=tL, lambduh=lam, prior_mean=-0.2, prior_var=1.3, y=y, weights=w, theta=theta,
+                          z0=z0, u=u, z=z))
+        refs.append(po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel,
+                                 pf="filter" if smoother == "filter" else "nemeth", lambduh=lam, stat=stat,
+                                 t1=t1, tL=tL, weights=w, prior_mean=-0.2, prior_var=1.3))
+    # one launch per statistic / smoother family is not required: a batch may mix them
+    outs = ctx.run_batch(probs, want_final=True)
+    for q, o, r in zip(probs, outs, refs):
+        tag = str((model, kernel, variant, q["N"], q["y"].shape[0], q["t1"], q["tL"], q["smoother"], q["lambduh"], q["stat"]))
+        np.testing.assert_allclose(o["x_t"], r["x_t"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        np.testing.assert_allclose(o["log_weights"], r["log_weights"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        ref = r["statistics"] if q["smoother"] == "filter" else r["mean_statistic"]
+        np.testing.assert_allclose(o["mean_stat"], ref, rtol=RTOL, atol=1e-8, err_msg=tag)
+        assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= ATOL + RTOL * abs(r["loglikelihood_estimate"]), tag
