@@ -59,7 +59,11 @@ class ChainEnsemble(object):
     """C independent SGLD chains of one model on one series, resident on `device`.
 
     Args:
-      model: 'svm' | 'garch' | 'lgssm';  observations: (T,) or (T,1)
+      model: 'svm' | 'garch' | 'lgssm';  observations: (T,) or (T,1), or a LIST of such arrays =
+             independent sequences (the Seq*Sampler setting, e.g. the gap-split EURUS segments):
+             every chain and step draws ONE sequence uniformly (num_sequences = 1) and a buffered
+             window inside it, its gradient rescaled by T_total / T_sequence
+             (sgmcmc_sampler.py:1249-1283)
       parameters: a Parameters object (all chains start there) or an array [C, P] of raw thetas
       num_chains: C (ignored when `parameters` is an array)
       N, pf ('poyiadjis_N' | 'nemeth'), lambduh, kernel: particle-filter settings
@@ -106,7 +110,16 @@ class ChainEnsemble(object):
         self.window_sampling = window_sampling
         self._graphs = {}
 
-        y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
+        self.segments = None
+        if isinstance(observations, (list, tuple)):
+            segs = [np.ascontiguousarray(o, dtype=np.float64).reshape(-1) for o in observations]
+            if len(segs) == 0 or min(len(o) for o in segs) == 0:
+                raise ValueError("every sequence needs at least one observation")
+            bounds = np.concatenate([[0], np.cumsum([len(o) for o in segs])]).astype(np.int64)
+            self.segments = bounds                    # [K+1] offsets into the concatenated series
+            y = np.concatenate(segs)
+        else:
+            y = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1)
         self.T = y.shape[0]
         if isinstance(parameters, np.ndarray):
             theta0 = np.ascontiguousarray(parameters, dtype=np.float64).reshape(-1, self.P)
@@ -124,7 +137,12 @@ class ChainEnsemble(object):
         self.seed, self.chain_offset = int(seed), int(chain_offset)
 
         S, B = int(subsequence_length), int(buffer_length)
-        if S == -1 or self.T - S <= 0:
+        if self.segments is not None:
+            if window_sampling != "host":
+                raise NotImplementedError("sequence lists use host-side window sampling")
+            if S == -1:
+                S = int(np.max(np.diff(self.segments)))      # whole sequences
+        elif S == -1 or self.T - S <= 0:
             S = -1
         self.S, self.B = S, (self.T if B == -1 else B)
         self.partition_style = partition_style
@@ -139,7 +157,24 @@ class ChainEnsemble(object):
         self.momentum_dev = torch.zeros((self.C, _capi.MAX_THETA), dtype=torch.float64, device=dev)
         self.weights_dev = None
         self._weights_table = None
-        if S > 0:
+        if self.segments is not None:
+            # one weights block per sequence: rows = window starts (or the single whole-sequence
+            # row when the sequence is no longer than S), every row pre-multiplied by
+            # T_total / T_sequence -- the Seq sampler's rescaling of a one-sequence gradient
+            blocks, offs, off = [], [], 0
+            for k in range(len(self.segments) - 1):
+                Tk = int(self.segments[k + 1] - self.segments[k])
+                scale = self.T / float(Tk)
+                if Tk - S <= 0:
+                    blk = np.ones((1, Tk)) * scale
+                else:
+                    blk = np.stack([self._weights_for(st, T=Tk) for st in range(Tk - S + 1)]) * scale
+                offs.append(off)
+                off += blk.size
+                blocks.append(blk.reshape(-1))
+            self._seg_weight_offsets = np.array(offs, dtype=np.int64)
+            self.weights_dev = torch.from_numpy(np.concatenate(blocks)).to(dev)
+        elif S > 0:
             # importance weights depend on the window start only: one resident row per start
             table = np.zeros((self.T - S + 1, S))
             for start in range(self.T - S + 1):
@@ -178,9 +213,9 @@ class ChainEnsemble(object):
         self.steps_done = 0
 
     # ------------------------------------------------------------------------------------
-    def _weights_for(self, start):
+    def _weights_for(self, start, T=None):
         """weights of random_subsequence_and_weights for a given start ('uniform' style)."""
-        S, T = self.S, self.T
+        S, T = self.S, (self.T if T is None else T)
         style = self.partition_style or 'uniform'
         if style in ('strict', 'naive'):
             return np.ones(S) * T / S
@@ -211,6 +246,27 @@ class ChainEnsemble(object):
         """Full sequence: static descriptors.  Buffered windows: draw one start per chain on the
         host (sgmcmc_sampler.py:259-288) and point y / weights / t1 / tL at it."""
         d = self._desc
+        if self.segments is not None:
+            # one sequence per chain (np.random.choice(K, 1)), then a window inside it
+            K = len(self.segments) - 1
+            seg = self._host_rng.randint(0, K, size=self.C)
+            base, Tk = self.segments[seg], self.segments[seg + 1] - self.segments[seg]
+            S, B = self.S, self.B
+            whole = Tk - S <= 0
+            span = np.where(whole, 1, Tk - S + 1)
+            if (self.partition_style or 'uniform') == 'strict':
+                start = np.where(whole, 0, (self._host_rng.random_sample(self.C) * np.maximum(Tk // S, 1)).astype(np.int64) * S)
+            else:
+                start = np.where(whole, 0, (self._host_rng.random_sample(self.C) * span).astype(np.int64))
+            length = np.where(whole, Tk, S)
+            left = np.maximum(0, start - B)
+            right = np.minimum(Tk, start + length + B)
+            d["y"] = self.y_dev.data_ptr() + (base + left).astype(np.uint64) * 8
+            d["T"] = right - left
+            d["t1"] = start - left
+            d["tL"] = start + length - left
+            d["weights"] = self.weights_dev.data_ptr() + (self._seg_weight_offsets[seg] + start * length).astype(np.uint64) * 8
+            return True
         if self.S == -1:
             if first:
                 d["y"] = self.y_dev.data_ptr()

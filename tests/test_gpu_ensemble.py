@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import pf_oracle as po
-from test_host_logic import default_params, GEN, PRIORS
+from test_host_logic import default_params, GEN, PRIORS, vec
 
 pytestmark = pytest.mark.gpu
 
@@ -271,3 +271,45 @@ def test_device_generator_normals_and_uniform_streams(N):
     again = ctx.run_batch(probs[:80], want_final=True)
     assert np.array_equal(again[0]["x_t"], outs[0]["x_t"]) and np.array_equal(again[79]["x_t"], outs[79]["x_t"])
     assert not np.array_equal(again[1]["x_t"], outs[0]["x_t"])
+
+
+def test_sequence_list_ensemble_matches_seq_sampler():
+    """ChainEnsemble over a LIST of sequences (the Seq*Sampler / EURUS-segments setting): every
+    chain and step draws one sequence and a buffered window inside it, the gradient rescaled by
+    T_total / T_sequence through the resident weights.  Descriptor invariants, and the mean
+    gradient over 4096 chains against SeqSVMSampler._noisy_grad_loglikelihood(num_sequences=1)."""
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.models.svm import SeqSVMSampler
+    p = default_params("svm")
+    np.random.seed(6)
+    y = GEN["svm"](T=137, parameters=p)["observations"]
+    cuts = [0, 40, 52, 77, 137]                      # lengths 40, 12 (<= S: whole sequence), 25, 60
+    seqs = [y[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    S, B, C, N = 16, 4, 4096, 128
+    ens = ChainEnsemble("svm", seqs, p, num_chains=C, N=N, epsilon=1e-3, subsequence_length=S, buffer_length=B,
+                        seed=21)
+    ens.step(1)                                      # second draw of windows happens inside step()
+    ens.synchronize()
+    d = ens._desc
+    left = (d["y"].astype(np.int64) - ens.y_dev.data_ptr()) // 8
+    seg = np.searchsorted(np.array(cuts), left, side="right") - 1
+    lo, hi = np.array(cuts)[seg], np.array(cuts)[seg + 1]
+    assert np.all(left + d["T"] <= hi) and np.all(left >= lo)             # windows never cross a sequence
+    assert set(np.unique(seg)) == {0, 1, 2, 3}
+    short = (hi - lo) <= S
+    assert np.all(d["tL"][short] - d["t1"][short] == (hi - lo)[short]) and np.all(d["tL"][~short] - d["t1"][~short] == S)
+    g, _ = ens.last_gradient_statistics()
+    # reference semantics through the drop-in Seq sampler (device generator), 600 draws
+    sampler = SeqSVMSampler(n=1, m=1, observations=seqs, parameters=p.copy())
+    np.random.seed(3)
+    ref = np.array([vec("svm", sampler._noisy_grad_loglikelihood(
+        num_sequences=1, kind="pf", pf="poyiadjis_N", N=N, subsequence_length=S, buffer_length=B, rng="device"))
+        for _ in range(600)])
+    got = g[:, [2, 1, 0]]                            # score columns [LRinv, LQinv, A] -> var_dict order
+    se = np.sqrt(got.var(axis=0) / C + ref.var(axis=0) / len(ref))
+    z = np.abs(got.mean(axis=0) - ref.mean(axis=0)) / se
+    assert np.all(z < 5.0), (z, got.mean(axis=0), ref.mean(axis=0))
+    assert np.all(np.isfinite(ens.theta()))
+    with pytest.raises(NotImplementedError):
+        ChainEnsemble("svm", seqs, p, num_chains=4, N=N, subsequence_length=S, buffer_length=B, window_sampling="device")
