@@ -26,7 +26,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 def _contract(src):
     """REPLAY kernels keep the reference's NumPy operation order (no fused multiply-add unless
     written as fma()); the device-generator kernels have no such parity to keep and fuse."""
-    return ["-ffp-contract=fast", "-DPFG_FAST_ALGEBRA=1"] if src.endswith("_device.hip") else ["-ffp-contract=off"]
+    return ["-ffp-contract=fast", "-DPFG_FAST_ALGEBRA=1"] + os.environ.get("PFG_EXTRA_DEVICE_FLAGS", "").split() if src.endswith("_device.hip") else ["-ffp-contract=off"]
 
 
 def _hipcc():
