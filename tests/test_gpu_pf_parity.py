@@ -354,3 +354,48 @@ def test_randomised_windows_every_variant(ctx, monkeypatch, model, kernel, varia
         ref = r["statistics"] if q["smoother"] == "filter" else r["mean_statistic"]
         np.testing.assert_allclose(o["mean_stat"], ref, rtol=RTOL, atol=1e-8, err_msg=tag)
         assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= ATOL + RTOL * abs(r["loglikelihood_estimate"]), tag
+
+
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("garch", "prior"), ("lgssm", "optimal")])
+def test_degenerate_weights_and_outliers(ctx, monkeypatch, model, kernel):
+    """Observations with 40-sigma outliers and exact zeros: log-weights hundreds of units below
+    zero, one particle carrying (almost) all the weight.  REPLAY fp64 stays on the oracle; the
+    device-generator variants (32-bit CDF, thread-major order, f32-unit normals) stay finite and
+    agree with each other on the log-likelihood within Monte-Carlo error."""
+    from test_host_logic import default_params
+    theta = default_params(model).theta()
+    rs = np.random.RandomState(12)
+    T = 14
+    y = rs.normal(size=T) * 0.5
+    y[3], y[4], y[9] = 40.0, 0.0, -35.0
+    monkeypatch.delenv("PFGRAD_VARIANT", raising=False)
+    for N in (100, 1000, 3000):
+        z0, u, z = po.draw_streams(rs, N, T)
+        q = dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f64", rng="replay", N=N, t1=0,
+                 tL=T, lambduh=1.0, prior_mean=0.0, prior_var=1.0, y=y, theta=theta, z0=z0, u=u, z=z)
+        o = ctx.run_batch([q])[0]
+        r = po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel, pf="poyiadjis_N", stat="score",
+                         prior_mean=0.0, prior_var=1.0)
+        assert np.all(np.isfinite(r["mean_statistic"]))
+        np.testing.assert_allclose(o["mean_stat"], r["mean_statistic"], rtol=1e-7, atol=1e-7)
+        # the reference's log(mean(exp(logw))) is not max-stabilised and underflows to -inf on the
+        # outlier steps of the GARCH prior kernel; the kernel's m + log(W/N) stays finite
+        # (DESIGN.md section 2, deviation (i))
+        ref_ll = r["loglikelihood_estimate"]
+        assert np.isfinite(o["loglik"])
+        if np.isfinite(ref_ll):
+            assert abs(o["loglik"] - ref_ll) <= 1e-8 * abs(ref_ll)
+        lls = {}
+        for dtype in ("f64", "f32"):
+            probs = [dict(q, rng="device", dtype=dtype, seed=4, stream=b) for b in range(64 if N < 2000 else 80)]
+            for p_ in probs:
+                for k in ("z0", "u", "z"):
+                    p_.pop(k)
+            outs = ctx.run_batch(probs)
+            ll = np.array([o_["loglik"] for o_ in outs])
+            ms = np.array([o_["mean_stat"] for o_ in outs])
+            assert np.all(np.isfinite(ll)) and np.all(np.isfinite(ms)), (model, N, dtype)
+            lls[dtype] = ll
+        se = np.sqrt(lls["f64"].var() / len(lls["f64"]) + lls["f32"].var() / len(lls["f32"])) + 1e-6
+        assert abs(lls["f64"].mean() - lls["f32"].mean()) < 6 * se + 2e-4 * abs(lls["f64"].mean())
+        assert abs(lls["f64"].mean() - o["loglik"]) < 8 * lls["f64"].std() + 1.0
