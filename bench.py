@@ -54,6 +54,40 @@ def make_workload(model):
     raise ValueError(model)
 
 
+def grad_error_vs_reference():
+    """The second half of BASELINE.json's metric: gradient L2 error vs the reference on identical
+    seeds.  Runs the HIP path (REPLAY generator, fp64) on the reference's own known-answer case
+    committed under tests/golden (SVM T=1000 N=1000, np.random.seed(99): the SURVEY 8c vector,
+    produced by the reference itself) and returns the errors.  No oracle involved."""
+    from sgmcmc_ssm_amd import _capi
+    path = os.path.join(ROOT, "tests", "golden", "pf_window.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    meta = [m for m in json.loads(str(g["meta"])) if m["key"] == "w0"][0]
+    N, T = meta["N"], meta["T"]
+    rs = np.random.RandomState(meta["seed"])      # the reference's consumption order of the legacy stream
+    z0 = rs.normal(size=N)
+    u, z = np.empty((T, N)), np.empty((T, N))
+    for t in range(T):
+        u[t] = rs.random_sample(N)
+        z[t] = rs.normal(size=N)
+    q = dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="replay", N=N, t1=0,
+             tL=T, lambduh=1.0, prior_mean=meta["prior_mean"], prior_var=meta["prior_var"], y=g["w0/y"],
+             theta=g["w0/theta"], z0=z0, u=u, z=z)
+    o = _capi.default_context(torch_device_index()).run_batch([q])[0]
+    ref = g["w0/mean_statistic"]
+    return {"grad_l2_err_vs_ref": float(np.linalg.norm(o["mean_stat"] - ref)),
+            "grad_l2_ref_norm": float(np.linalg.norm(ref)),
+            "loglik_abs_err_vs_ref": float(abs(o["loglik"] - float(g["w0/loglikelihood_estimate"]))),
+            "case": "SVM T=1000 N=1000, np.random.seed(99), reference fixture tests/golden/pf_window.npz:w0, REPLAY fp64"}
+
+
+def torch_device_index():
+    import torch
+    return torch.cuda.current_device()
+
+
 def cpu_baseline(model, p0, y, prior, cfg, budget_s=12.0):
     """Reference CPU path: SGLD steps/s of ONE chain with the NumPy oracle (bit-identical to the
     reference's arithmetic), single thread.  Bounded: >= 3 steps, about `budget_s` seconds."""
@@ -253,6 +287,8 @@ def main():
                 "valu_issue": valu,
             },
         }
+        if world == 1 and not args.no_single_chain:
+            line["parity"] = grad_error_vs_reference()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, p0, y, prior, cfg, budget_s=args.cpu_budget)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
