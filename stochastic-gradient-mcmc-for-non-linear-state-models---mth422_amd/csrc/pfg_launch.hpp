@@ -26,6 +26,7 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
         case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
         case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
         case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
+        case 5: return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, true>(ctx, n_max, B, dp, st);
         case 4:
             if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st);
             break;

@@ -48,7 +48,7 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
 // 256x4 fp64: ping-pong state is 80 KB/workgroup -> 2 workgroups (2 waves/SIMD); the single
 // buffer is 50 KB -> 3, which is worth a few spilled registers (measured +15 %).
 __host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
-    return (NT >= 512 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
+    return (NT >= 512 || NT == 64 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
 }
 __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
     return dev4 ? 4 : ((NT == 256 && PPT == 4 && !PP) ? 3 : 1);

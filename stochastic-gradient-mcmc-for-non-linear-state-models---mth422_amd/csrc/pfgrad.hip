@@ -37,8 +37,10 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               {1024, 1, true, "wg1024x1"},
                               // 1024 < N <= 4096 with the device generator when the state fits LDS
                               // (32-bit CDF): SVM fp64, every model in f32
-                              {1024, 4, false, "wg1024x4s"} };
-constexpr int kLds4096Variant = 4;
+                              {1024, 4, false, "wg1024x4s"},
+                              // N <= 128: one wave per window (barriers and cross-wave reductions degenerate)
+                              {64, 2, true, "wg64x2"} };
+constexpr int kLds4096Variant = 4, kTinyVariant = 5;
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -71,6 +73,11 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
     // preference order: fp64 N<=1024 runs best on the single-buffer 256x4 variant at 3
     // workgroups per CU; f32 on ping-pong.  N > 1024 goes to the large-N kernel: 1024-thread
     // register-resident variants spill at the 128-VGPR cap and measured 3-5x slower than it.
+    // N <= 128, many windows: one wave per window (2048 LGSSM N=100 T=200 chains: 1.07 -> 0.57 ms);
+    // a lone window is quicker on the four waves of wg256x1 (0.34 vs 0.38 ms)
+    if (n_max <= 128 && batch > kLatencyBatch &&
+        lds_bytes(model, dtype, rng, kVariants[kTinyVariant], n_max) <= kLdsLimit)
+        return kTinyVariant;
     if (batch <= kLatencyBatch && n_max > 256 && n_max <= 1024 &&
         lds_bytes(model, dtype, rng, kVariants[kLatencyVariant], n_max) <= kLdsLimit)
         return kLatencyVariant;

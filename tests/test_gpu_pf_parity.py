@@ -315,7 +315,7 @@ def test_large_n_device_rng_fast_kernel(ctx, monkeypatch, model, kernel, theta, 
     assert np.array_equal(o1["mean_stat"], o2["mean_stat"]) and o1["loglik"] == o2["loglik"]
 
 
-@pytest.mark.parametrize("variant", ["auto", "wg256x4", "wg256x4s", "wg1024x1", "mem1024"])
+@pytest.mark.parametrize("variant", ["auto", "wg256x4", "wg256x4s", "wg1024x1", "wg64x2", "mem1024"])
 @pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "prior"), ("garch", "optimal"),
                                           ("lgssm", "prior"), ("lgssm", "optimal")])
 def test_randomised_windows_every_variant(ctx, monkeypatch, model, kernel, variant):
