@@ -59,12 +59,17 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 #ifndef PFG_OCC4
 #define PFG_OCC4 1
 #endif
+// GARCH fp64 single buffer: six state arrays = 56.8 KB of LDS -> two workgroups per CU whatever
+// the registers; give the allocator the 256 VGPRs that occupancy leaves (168 -> 32 spills)
+__host__ __device__ constexpr bool occ_two(int MODEL, int NT, int PPT, size_t real, bool PP) {
+    return MODEL == PFG_MODEL_GARCH && real == 8 && NT == 256 && PPT == 4 && !PP;
+}
 __host__ __device__ constexpr bool occ_dev4(int MODEL, int NT, int PPT, int RNG, bool PP, int MODE) {
     return PFG_OCC4 && MODEL == PFG_MODEL_SVM && NT == 256 && PPT == 4 && !PP && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN;
 }
 
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_min(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE)), occ_max(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE))))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_min(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE)), occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_max(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE))))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr bool PARIS = (MODE == MODE_PARIS);
     constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
     constexpr bool N2 = (MODE == MODE_N2);
