@@ -313,3 +313,39 @@ def test_sequence_list_ensemble_matches_seq_sampler():
     assert np.all(np.isfinite(ens.theta()))
     with pytest.raises(NotImplementedError):
         ChainEnsemble("svm", seqs, p, num_chains=4, N=N, subsequence_length=S, buffer_length=B, window_sampling="device")
+
+
+def test_full_size_workload_device_vs_replay():
+    """BASELINE's full size (SVM T=1000, N=1000), the bench workload itself: the device-generator
+    kernel the bench times (wg256x4s, 32-bit CDF, thread-major order, f32-unit normals, fused
+    math) against the REPLAY kernel that is pinned bit-level to the reference, as estimators of the
+    same score / log-likelihood: means over 3072 device chains vs 48 replayed seeds within 5
+    standard errors, comparable spread, and the log-likelihood identity E[exp(ll)] (both unbiased)."""
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.particle_filters import draw_replay_streams
+    p = default_params("svm")
+    np.random.seed(12345)
+    y = GEN["svm"](T=1000, parameters=p)["observations"]
+    C, N, R = 3072, 1000, 48
+    ens = ChainEnsemble("svm", y, p, num_chains=C, N=N, epsilon=1e-4, seed=77)
+    assert ens.ctx.variant_name("svm", "prior", "f64", "device", N) == "wg256x4s"
+    ens.launch_pf()
+    ens.synchronize()
+    g, ll = ens.last_gradient_statistics()
+    got = np.column_stack([g, ll])
+    ctx = _capi.default_context(0)
+    rs = np.random.RandomState(5)
+    ref = []
+    for _ in range(R):
+        z0, u, z = draw_replay_streams(N, 1000, rs)
+        o = ctx.run_batch([dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64",
+                                rng="replay", N=N, t1=0, tL=1000, lambduh=1.0, prior_mean=0.0, prior_var=10.0,
+                                y=y.reshape(-1), theta=p.theta(), z0=z0, u=u, z=z)])[0]
+        ref.append(np.append(o["mean_stat"], o["loglik"]))
+    ref = np.array(ref)
+    se = np.sqrt(got.var(axis=0) / C + ref.var(axis=0) / R)
+    zscore = np.abs(got.mean(axis=0) - ref.mean(axis=0)) / se
+    assert np.all(zscore < 5.0), (zscore, got.mean(axis=0), ref.mean(axis=0))
+    ratio = got.std(axis=0) / ref.std(axis=0)
+    assert np.all((ratio > 0.6) & (ratio < 1.6)), ratio
