@@ -127,10 +127,19 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
             lw = (c.c0 + (-half * (diff * diff)) * c.Rinv) + c.logLRinv;
         } else {
             // lgssm/kernels.py:87-97, :117-120
+#ifdef PFG_FAST_ALGEBRA
+            // device-generator units: the two divisors are wave-uniform -> reciprocals, once per step
+            const REAL rprec = (REAL)1 / c.opt_prec, rvar = (REAL)1 / c.opt_var;
+            REAL mp = (xp[0] * c.A) * c.Qinv + (y * c.C) * c.Rinv;
+            x1 = fma(c.opt_sd, z, mp * rprec);
+            REAL diff = y - c.A * xp[0];
+            lw = fma(-half * (diff * diff), rvar, -half * (REAL)LOG_2PI - half * c.opt_logvar);
+#else
             REAL mp = (xp[0] * c.A) * c.Qinv + (y * c.C) * c.Rinv;
             x1 = c.opt_sd * z + mp / c.opt_prec;
             REAL diff = y - c.A * xp[0];
             lw = ((-half * (diff * diff)) / c.opt_var - half * (REAL)LOG_2PI) - half * c.opt_logvar;
+#endif
         }
         xn[0] = x1;
         if (STAT == PFG_STAT_SCORE) {
