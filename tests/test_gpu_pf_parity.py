@@ -108,7 +108,7 @@ def test_window_cases_f64_large_n_kernel(ctx, golden_window, force_mem_kernel):
     test_window_cases_f64(ctx, golden_window)
 
 
-@pytest.mark.parametrize("variant", ["wg256x4", "wg256x4s", "wg1024x1"])
+@pytest.mark.parametrize("variant", ["wg256x4", "wg256x4s", "wg1024x1", "wg64x2"])
 def test_reference_cases_on_every_lds_variant(ctx, golden_trace, golden_window, monkeypatch, variant):
     """Single windows with 256 < N <= 1024 are served by the latency variant (wg1024x1), large
     batches by the throughput variants; every variant must reproduce the reference fixtures, so
@@ -399,3 +399,37 @@ def test_degenerate_weights_and_outliers(ctx, monkeypatch, model, kernel):
         se = np.sqrt(lls["f64"].var() / len(lls["f64"]) + lls["f32"].var() / len(lls["f32"])) + 1e-6
         assert abs(lls["f64"].mean() - lls["f32"].mean()) < 6 * se + 2e-4 * abs(lls["f64"].mean())
         assert abs(lls["f64"].mean() - o["loglik"]) < 8 * lls["f64"].std() + 1.0
+
+
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal"), ("lgssm", "prior")])
+def test_one_wave_variant_replay_parity(ctx, monkeypatch, model, kernel):
+    """wg64x2 (N <= 128, one wave per window) is what launches of more than 64 small windows run
+    on: 70 ragged windows in one launch, REPLAY fp64 vs the oracle, plus the fully traced
+    reference fixtures (N = 32) forced onto it."""
+    from test_host_logic import default_params
+    monkeypatch.delenv("PFGRAD_VARIANT", raising=False)
+    theta = default_params(model).theta()
+    rs = np.random.RandomState(31)
+    probs, refs = [], []
+    for b in range(70):
+        N = int(rs.choice([1, 2, 5, 63, 64, 65, 100, 127, 128]))
+        T = int(rs.choice([0, 1, 4, 11]))
+        t1 = int(rs.randint(0, T + 1))
+        tL = int(rs.randint(t1, T + 1))
+        y = rs.normal(size=T) * (1.2 if model != "garch" else 0.6)
+        w = rs.uniform(0.5, 5.0, size=tL - t1) if b % 3 == 0 else None
+        z0, u, z = po.draw_streams(rs, N, T)
+        smoother, lam = [("nemeth", 1.0), ("nemeth", 0.8), ("filter", 1.0)][b % 3]
+        probs.append(dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="replay", N=N,
+                          t1=t1, tL=tL, lambduh=lam, prior_mean=0.2, prior_var=0.9, y=y, weights=w, theta=theta,
+                          z0=z0, u=u, z=z))
+        refs.append(po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel,
+                                 pf="filter" if smoother == "filter" else "nemeth", lambduh=lam, stat="score",
+                                 t1=t1, tL=tL, weights=w, prior_mean=0.2, prior_var=0.9))
+    assert ctx.variant_name(model, kernel, "f64", "replay", 128) == "wg64x2"
+    outs = ctx.run_batch(probs, want_final=True)
+    for q, o, r in zip(probs, outs, refs):
+        np.testing.assert_allclose(o["x_t"], r["x_t"], rtol=RTOL, atol=ATOL)
+        ref = r["statistics"] if q["smoother"] == "filter" else r["mean_statistic"]
+        np.testing.assert_allclose(o["mean_stat"], ref, rtol=RTOL, atol=1e-8)
+        assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= ATOL + RTOL * abs(r["loglikelihood_estimate"])
