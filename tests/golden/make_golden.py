@@ -416,7 +416,9 @@ def make_latent_fixtures():
     for ci, (model, kernel, pf, N, T, t1, tL) in enumerate([
             ("svm", None, "poyiadjis_N", 200, 30, 0, None), ("svm", "prior", "poyiadjis_N", 64, 20, 4, 16),
             ("lgssm", None, "poyiadjis_N", 150, 25, 0, None), ("lgssm", "prior", "poyiadjis_N", 100, 18, 2, 18),
-            ("garch", None, "poyiadjis_N", 120, 22, 0, None), ("garch", "prior", "poyiadjis_N", 80, 16, 3, 12)]):
+            ("garch", None, "poyiadjis_N", 120, 22, 0, None), ("garch", "prior", "poyiadjis_N", 80, 16, 3, 12),
+            ("svm", None, "nemeth", 150, 24, 0, None), ("lgssm", None, "nemeth", 90, 20, 3, 17),
+            ("garch", None, "nemeth", 100, 18, 2, 15)]):
         cfg = MODEL_SETUP[model]
         p = cfg["params"]()
         np.random.seed(900 + ci)

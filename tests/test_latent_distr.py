@@ -21,7 +21,7 @@ def _kw(meta):
 
 def test_oracle_elementwise_matches_reference(golden_latent):
     g = golden_latent
-    assert len(g.meta) == 6
+    assert len(g.meta) == 9
     for m in g.meta:
         rng = np.random.RandomState(m["seed"])
         xm, xc = po.latent_var_distr(m["model"], g.get(m["key"], "theta"), g.get(m["key"], "y"), m["N"], rng=rng, **_kw(m))
@@ -44,6 +44,18 @@ def test_lineage_tracing_equals_elementwise_statistics(golden_latent):
         tL = T if m["tL"] is None else m["tL"]
         streams = po.draw_streams(np.random.RandomState(m["seed"]), N, T)
         kw = _kw(m)
+        if m["pf"] == "nemeth":
+            # Nemeth shrinkage: the forward recursion replayed on the host over the recorded
+            # trajectory (product code) vs the oracle's elementwise run, two lambdas, +- weights
+            for lam, weights in ((None, None), (0.7, np.linspace(1.0, 2.0, tL - m["t1"]))):
+                out = po.pf_window(m["model"], g.get(m["key"], "theta"), y, N, *streams, stat="suff",
+                                   elementwise_statistic=True, save_all=True, weights=weights, lambduh=lam, **kw)
+                stats, avg = particle_filters.nemeth_elementwise_statistics(
+                    m["model"], np.array(out["all_x_t"]), np.array(out["all_ancestors"]),
+                    np.array(out["all_log_weights"]), m["t1"], tL, 0.95 if lam is None else lam, weights)
+                assert np.array_equal(stats, out["statistics"]), m
+                assert np.array_equal(avg, out["mean_statistic"]), m
+            continue
         out = po.pf_window(m["model"], g.get(m["key"], "theta"), y, N, *streams, stat="suff",
                            elementwise_statistic=True, save_all=True, **kw)
         w = np.linspace(1.0, 2.0, tL - m["t1"])
@@ -80,12 +92,12 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
             np.random.seed(m["seed"])
             xm, xc = helper.pf_latent_var_distr(observations=g.get(m["key"], "y").reshape(-1, 1), parameters=p,
                                                 subsequence_start=m["t1"], subsequence_end=m["tL"], N=m["N"],
-                                                kernel=m["kernel"], squared=True)
+                                                pf=m["pf"], kernel=m["kernel"], squared=True)
             np.testing.assert_allclose(xm, g.get(m["key"], "x_mean_sq"), rtol=1e-9, atol=1e-9)
     with pytest.raises(ValueError):
         helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, lag=0)
     with pytest.raises(NotImplementedError):
-        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="nemeth")
+        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="paris")
 
 
 @pytest.mark.gpu
