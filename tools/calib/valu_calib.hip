@@ -1,0 +1,98 @@
+// VALU issue calibration for gfx950: known instruction streams (v_fma_f64 / v_fma_f32 / v_exp_f32 /
+// v_xor_b32 / a 50:50 f64:b32 mix) at 1, 2 and 4 waves per SIMD.  Prints, per case, the cycles one
+// SIMD spends per wave-instruction (from s_memtime inside the kernel and from hipEvents), and is
+// run under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...` to read what the
+// counters report for a stream whose instruction count and duration are known.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/calib/valu_calib.hip -o tools/calib/valu_calib
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int UNROLL = 16;     // independent accumulators per lane
+
+template <int KIND>
+__global__ __launch_bounds__(256) void stream_kernel(int iters, double *out, unsigned long long *cyc) {
+    extern __shared__ unsigned char pad[];
+    double a64[UNROLL];
+    float a32[UNROLL];
+    unsigned u32[UNROLL];
+    const double b64 = 1.0000001, c64 = 1e-9;
+    const float b32 = 1.0001f, c32 = 1e-6f;
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) { a64[j] = threadIdx.x + j; a32[j] = threadIdx.x + j; u32[j] = threadIdx.x * 7 + j; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            if (KIND == 0) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a64[j]) : "v"(b64), "v"(c64));
+            if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a32[j]) : "v"(b32), "v"(c32));
+            if (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a32[j]));
+            if (KIND == 3) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u32[j]) : "v"(u32[(j + 1) % UNROLL]));
+            if (KIND == 4) {   // alternate f64 / b32
+                if (j & 1) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a64[j]) : "v"(b64), "v"(c64));
+                else asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u32[j]) : "v"(u32[(j + 2) % UNROLL]));
+            }
+            if (KIND == 5) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a64[j]) : "v"(c64));
+            if (KIND == 6) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a64[j]) : "v"(b64));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) s += a64[j] + (double)a32[j] + (double)u32[j];
+    if (s == 123.456) out[0] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char *name, int blocks_per_cu, int iters) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    const int grid = cus * blocks_per_cu;
+    const size_t lds = (size_t)(160 * 1024 / blocks_per_cu) - 1024;     // pins blocks_per_cu workgroups per CU
+    double *out; unsigned long long *cyc;
+    CK(hipMalloc(&out, 8)); CK(hipMalloc(&cyc, (size_t)grid * 4 * 8));
+    auto k = stream_kernel<KIND>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, iters / 8, out, cyc);   // warm-up
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, iters, out, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h((size_t)grid * 4);
+    CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[h.size() / 2];
+    const double inst_per_wave = (double)iters * UNROLL;
+    // waves per SIMD = blocks_per_cu (256 threads = 4 waves = one per SIMD)
+    const double cyc_per_inst_simd = med / (inst_per_wave * blocks_per_cu);
+    const double total_inst = inst_per_wave * 4.0 * grid;
+    printf("%-14s waves/SIMD %d  grid %5d  %8.3f ms  wave-cycles(median, s_memtime) %.3e  => %.2f SIMD-cycles per wave-instruction"
+           "  [events: %.2f at 2.4 GHz]  wave-instructions %.4e\n",
+           name, blocks_per_cu, grid, ms, med, cyc_per_inst_simd,
+           ms * 1e-3 * 2.4e9 * cus * 4 / total_inst, total_inst);
+    CK(hipFree(out)); CK(hipFree(cyc));
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 200000;
+    for (int w : {1, 2, 4}) {
+        run<0>("v_fma_f64", w, iters);
+        run<5>("v_add_f64", w, iters);
+        run<6>("v_mul_f64", w, iters);
+        run<1>("v_fma_f32", w, iters);
+        run<2>("v_exp_f32", w, iters);
+        run<3>("v_xor_b32", w, iters);
+        run<4>("f64:b32 1:1", w, iters);
+    }
+    return 0;
+}
