@@ -29,10 +29,11 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 100          /* 0.1.0 */
+#define PFG_VERSION 110          /* 0.1.1 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
+#define PFG_STAMP_WORDS 16       /* uint64 words behind pfg_dev_problem.stamps */
 #define PFG_MAX_PRED 16          /* predictive log-likelihood leads k = 0..num_steps_ahead (<= 15) */
 
 typedef struct pfg_ctx pfg_ctx;
@@ -130,6 +131,12 @@ typedef struct pfg_result {
     int32_t *trace_anc; /* [T*N] ancestor index of every particle at every step (with trace_x):
                            the genealogy, from which smoothed marginals are traced back */
     double pred[PFG_MAX_PRED]; /* PFG_STAT_PREDICTIVE: out['statistics'][k] of the reference */
+    /* DEVICE rng + trace_x only (test instrumentation of the device-generator kernels): the random
+     * inputs the kernel drew, so that a CPU oracle can replay the SAME launch deterministically.
+     * rec_u [T*N]: the raw 32-bit word child i searched the resampling CDF with at step t;
+     * rec_z [T*N]: its standard normal (as widened to f64);  rec_z0 [N]: the x0 normals. */
+    uint32_t *rec_u;
+    double *rec_z, *rec_z0;
 } pfg_result;
 
 /* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
@@ -160,6 +167,12 @@ typedef struct pfg_dev_problem {
     double *pred_out;        /* PREDICTIVE: [PFG_MAX_PRED] */
     void *pred_scratch;      /* PREDICTIVE: [N][PFG_MAX_PRED] of the state type */
     int32_t num_steps_ahead, reserved3;
+    uint32_t *rec_u;         /* [T*N] or NULL: see pfg_result.rec_u (DEVICE rng, with trace_x) */
+    double *rec_z, *rec_z0;  /* [T*N], [N] or NULL */
+    uint64_t *stamps;        /* [PFG_STAMP_WORDS] or NULL (measurement): wave 0 of the workgroup writes
+                                s_memtime / s_memrealtime (100 MHz) at kernel start [0],[1] and end [2],[3]
+                                -> in-kernel shader clock = ([2]-[0]) / ([3]-[1]) * 100 MHz; [4..15]: per-phase
+                                cycle sums, only in diagnostic builds (-DPFG_PHASE_STAMPS), else untouched */
 } pfg_dev_problem;
 
 int pfg_version(void);
@@ -208,6 +221,10 @@ int pfg_sample_windows_device(pfg_ctx *ctx, int B, pfg_dev_problem *dev_probs, c
 int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N);
 /* name of the kernel variant pfg_launch_device would pick (for profiles / logs) */
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max);
+/* tag of the kernel variant the latest launch through this context ran ("wg256x4s", "wg1024x1",
+ * "wg1024x4s", "wg64x2", "big4096", "big16384", "mem1024", ...): the batch size takes part in the
+ * choice, so tests and profiles read it back instead of predicting it */
+const char *pfg_last_variant(pfg_ctx *ctx);
 int pfg_synchronize(pfg_ctx *ctx);
 
 /* SGLD parameter update for B resident chains (sgmcmc_sampler.py:427-464, 529-566, 650-656):

@@ -104,6 +104,35 @@ def multinomial_ancestors(p, u):
     return np.searchsorted(cdf, u, side="right")
 
 
+def device_ancestors(logw, words, NT, PPT, cdf="fixed32"):
+    """Multinomial resampling as the DEVICE-generator kernels of libpfgrad lay it out (this is a
+    restatement of csrc/pfg_reg_kernel.hpp phases B-E / csrc/pfg_big_kernel.hpp, not of the
+    reference: the reference's resampling is `multinomial_ancestors`; both draw ancestors i.i.d.
+    from softmax(logw)).  The CDF runs over NT*PPT slots in THREAD-major order -- slot
+    q = tid*PPT + k holds particle k*NT + tid, slots of particles >= N weigh 0 -- and child i is
+    the count of CDF entries <= its own 32-bit word `words[i]`:
+      cdf='fixed32' (LDS-resident kernels): entries floor(min(cs/W * 2^32, 2^32 - 1)), integer compare;
+      cdf='f64'     (pf_big_kernel):        entries cs/W in f64 against (word + 0.5) / 2^32."""
+    N = logw.shape[0]
+    NP = NT * PPT
+    q = np.arange(NP)
+    particle = (q % PPT) * NT + q // PPT
+    p = np.exp(logw - np.max(logw))
+    w = np.where(particle < N, p[np.minimum(particle, N - 1)], 0.0)
+    cs = np.cumsum(w)
+    W = cs[-1]
+    if cdf == "fixed32":
+        table = np.floor(np.minimum(cs * ((1.0 / W) * 4294967296.0), 4294967295.0)).astype(np.uint64)
+        pos = np.searchsorted(table, words.astype(np.uint64), side="right")
+    elif cdf == "f64":
+        table = cs * (1.0 / W)
+        pos = np.searchsorted(table, (words.astype(np.float64) + 0.5) * (1.0 / 4294967296.0), side="right")
+    else:
+        raise ValueError(cdf)
+    pos = np.minimum(pos, NP - 1)
+    return np.minimum((pos % PPT) * NT + pos // PPT, N - 1)
+
+
 def sample_x0(model, prior_mean, prior_var, z0):
     """kernels.py:83-100 (n=1), garch/kernels.py:7-18.  z0: (N,) standard normals.
     np.random.normal(loc, scale) is loc + scale*gauss."""
@@ -397,7 +426,7 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
               lambduh=None, stat="score", t1=0, tL=None, weights=None,
               prior_mean=0.0, prior_var=1.0, save_all=False,
               Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None,
-              elementwise_statistic=False, num_steps_ahead=5, pred_normals=None):
+              elementwise_statistic=False, num_steps_ahead=5, pred_normals=None, resampler=None):
     """One buffered PF window.
 
     Args:
@@ -406,6 +435,9 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
       z0 (N,), u (T,N), z (T,N): the random streams (see draw_streams)
       pf: 'poyiadjis_N' (lambda=1), 'nemeth' (default lambda .95), 'filter'
       stat: 'score' | 'suff' | 'none'
+      resampler: None = the reference's np.random.choice semantics on u[t]; else a callable
+          (t, logw) -> ancestors (tests of the device-generator kernels: `device_ancestors` on the
+          words the launch recorded), u is then unused
     Returns dict(x_t, log_weights, statistics, loglikelihood_estimate[, mean_statistic, all_*])
     """
     y = np.asarray(y, dtype=float).reshape(-1, 1)   # y[t] is a (1,) array as in the reference
@@ -461,7 +493,10 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             # nemeth_smoother: S from the *previous* weights (pf.py:161)
             S = np.sum(stats.T * log_normalize(logw), axis=1)
         # pf(): resample every step, propose, weight (pf.py:26-38)
-        anc = multinomial_ancestors(log_normalize(logw), u[t])
+        if resampler is None:
+            anc = multinomial_ancestors(log_normalize(logw), u[t])
+        else:
+            anc = resampler(t, logw)
         if save_all:
             all_anc.append(anc)
         parents = x[anc]

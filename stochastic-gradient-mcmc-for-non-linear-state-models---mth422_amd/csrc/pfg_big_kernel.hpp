@@ -73,6 +73,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     tab_fill(tabmem, true, tid, NT);
 
     const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
+    if (P.stamps && tid == 0) { P.stamps[0] = __builtin_amdgcn_s_memtime(); P.stamps[1] = __builtin_amdgcn_s_memrealtime(); }
     LaneRng rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
     REAL lwr[LWREG ? CH2 : 1];
 #pragma unroll
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                 REAL a, b;
                 mth.normal_pair(rng.next(), rng.next(), a, b);
                 x[0] = (REAL)(P.prior_mean + sd * (double)a);
+                if (P.trace_x && P.rec_z0) P.rec_z0[i] = (double)a;
             }
             if (LWREG) lwr[LWREG ? jj : 0] = l0;
             else lwg[i] = l0;
@@ -249,10 +251,17 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                 for (int g = 0; g < G; ++g) {
                     i[g] = (j0 + g) * NT + tid;
                     v[g] = i[g] < N;
-                    u[g] = u01_32(rng.next());
+                    const uint32_t word = rng.next();
+                    u[g] = u01_32(word);
                     a[g] = 0;
+                    if (P.trace_x && P.rec_u && v[g]) P.rec_u[(size_t)t * N + i[g]] = word;
                 }
                 mth.normal_pair(rng.next(), rng.next(), z[0], z[1]);
+                if (P.trace_x && P.rec_z) {           // test instrumentation (see pfg_result.rec_z)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (v[g]) P.rec_z[(size_t)t * N + i[g]] = (double)z[g];
+                }
 #pragma unroll
                 for (int step = NP2 >> 1; step >= 1; step >>= 1) {
                     const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     }
 
     // ---- outputs --------------------------------------------------------------------------
+    if (P.stamps && tid == 0) { P.stamps[2] = __builtin_amdgcn_s_memtime(); P.stamps[3] = __builtin_amdgcn_s_memrealtime(); }
     if (tid == 0 && P.out) {
 #pragma unroll
         for (int h = 0; h < PFG_MAX_STAT; ++h) P.out[h] = 0.0;

@@ -42,6 +42,7 @@ struct pfg_ctx {
     pfg_host::Arena in, out, desc, scratch;
     std::vector<double> h_in, h_out;
     std::vector<pfg_dev_problem> h_desc;
+    const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched
 };
 
 namespace pfg_host {

@@ -141,6 +141,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
     int np2 = 1;
     while (np2 < N) np2 <<= 1;
+    // measurement hooks (pfg_dev_problem.stamps): shader-clock / 100 MHz stamps at start and end;
+    // per-phase cycle sums only in diagnostic builds
+    if (P.stamps && tid == 0) { P.stamps[0] = __builtin_amdgcn_s_memtime(); P.stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#ifdef PFG_PHASE_STAMPS
+    unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_prev = __builtin_amdgcn_s_memtime();
+#define PFG_PH(i) { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_now - ph_prev; ph_prev = ph_now; }
+#else
+#define PFG_PH(i)
+#endif
 
     LaneRng rng = {};
     if (RNG == PFG_RNG_DEVICE)
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 } else {
                     const double z = (RNG == PFG_RNG_REPLAY) ? P.z0[i] : (double)z0[k];
                     x[0] = (REAL)(P.prior_mean + sd * z);
+                    if (RNG == PFG_RNG_DEVICE && P.trace_x && P.rec_z0) P.rec_z0[i] = z;
                 }
 #pragma unroll
                 for (int d = 0; d < NS; ++d) cur[(size_t)d * NL + i] = x[d];
@@ -228,7 +239,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         for (int k = 1; k < PPT; ++k) ml = fmaxf(ml, (float)lw[k]);
         ml = wave_max(ml);
         if (lane == 0) red_maxf[wave] = ml;
+        PFG_PH(0)
         __syncthreads();                                                        // barrier 1
+        PFG_PH(1)
         {
             float mm = red_maxf[0];
 #pragma unroll
@@ -277,7 +290,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 zz[k] = (REAL)zv[(size_t)t * N + own[k]];
             }
         }
+        PFG_PH(2)
         __syncthreads();                                                        // barrier 2
+        PFG_PH(3)
         if (BLK) {
             // NW wave totals: exclusive prefix by a DPP scan over the first lanes
             const double tot = (lane < NW) ? red_scan[lane] : 0.0;
@@ -368,7 +383,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     if (PARIS || N2) lwL[k * NT + tid] = lw[k];
                 }
         }
+        PFG_PH(4)
         __syncthreads();                                                        // barrier 3
+        PFG_PH(5)
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
         // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
@@ -390,6 +407,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             uint32_t ua[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) ua[k] = rng.next();
+            if (P.trace_x && P.rec_u) {           // test instrumentation: the words this launch searched with
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    if (valid[k]) P.rec_u[(size_t)t * N + k * NT + tid] = ua[k];
+            }
 #pragma unroll
             for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
                 const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
@@ -436,6 +458,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 tie = (valid[k] && mg < tie) ? mg : tie;
             }
         }
+        PFG_PH(6)
         // ---- (F) gather parents, (G) propose / weight / statistic, (H) publish children ---
         auto slots = [&](auto stat_tag) {
             constexpr int STAT = decltype(stat_tag)::value;
@@ -447,8 +470,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
                 for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
             }
+            PFG_PH(7)
             if (!PP) __syncthreads();                                           // barrier 4 (single buffer)
-            if (RNG != PFG_RNG_REPLAY) draw_normals(zz);
+            PFG_PH(8)
+            if (RNG != PFG_RNG_REPLAY) {
+                draw_normals(zz);
+                if (P.trace_x && P.rec_z) {
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k)
+                        if (valid[k]) P.rec_z[(size_t)t * N + k * NT + tid] = (double)zz[k];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 REAL xn[NS], add[H], lwn;
@@ -842,7 +874,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         }
         if (PP) { REAL *tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
+        PFG_PH(9)
     }
+    if (P.stamps && tid == 0) { P.stamps[2] = __builtin_amdgcn_s_memtime(); P.stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#ifdef PFG_PHASE_STAMPS
+    if (P.stamps && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(P.stamps) + 4 + q, ph_acc[q]);
+    }
+#endif
+#undef PFG_PH
 
     // ---- outputs --------------------------------------------------------------------
     if (RNG == PFG_RNG_REPLAY && P.out) {

@@ -133,6 +133,12 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
         const char *force = std::getenv("PFGRAD_VARIANT");
         if (!(force && !std::strcmp(force, "mem1024"))) v = kVariantBig;
     }
+    ctx->last_variant = v >= 0 ? kVariants[v].tag
+                        : v == kVariantMem ? "mem1024"
+                        : v == kVariantBig ? (n_max <= 4096 ? "big4096" : "big16384")
+                        : v == kVariantParis ? (n_max <= 256 ? "paris256x1" : n_max <= 1024 ? "paris256x4" : "paris_mem1024")
+                        : v == kVariantSystematic ? "systematic256x4"
+                        : (n_max <= 256 ? "n2_256x1" : "n2_256x4");
     if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
     if (model == PFG_MODEL_GARCH) {
         if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
@@ -318,6 +324,8 @@ void pfg_destroy(pfg_ctx *ctx) {
     ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release();
     delete ctx;
 }
+
+const char *pfg_last_variant(pfg_ctx *ctx) { return ctx ? ctx->last_variant : "none"; }
 
 void *pfg_ctx_stream(pfg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
@@ -519,6 +527,13 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (r.trace_stats) n_out += (size_t)(q.T + 1) * q.N * H;
         if (r.trace_ll) n_out += (size_t)q.T + 1;
         if (r.trace_anc) n_out += ((size_t)q.T * q.N + 1) / 2;       /* int32 pairs in f64 slots */
+        if (r.rec_u || r.rec_z || r.rec_z0) {
+            if (rng != PFG_RNG_DEVICE || !r.trace_x)
+                return fail(ctx, PFG_ERR_INVALID, id + "rec_u / rec_z / rec_z0 record the DEVICE generator's draws and need trace_x");
+            if (r.rec_u) n_out += ((size_t)q.T * q.N + 1) / 2;
+            if (r.rec_z) n_out += (size_t)q.T * q.N;
+            if (r.rec_z0) n_out += q.N;
+        }
         if (r.trace_anc && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_anc needs trace_x");
         if ((r.logw_T || r.stats_T) && !r.x_T) return fail(ctx, PFG_ERR_INVALID, id + "logw_T/stats_T need x_T");
         if ((r.trace_logw == nullptr) != (r.trace_x == nullptr))
@@ -618,6 +633,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.trace_stats = take(r.trace_stats != nullptr, (size_t)(q.T + 1) * q.N * H);
         d.trace_ll = take(r.trace_ll != nullptr, (size_t)q.T + 1);
         d.trace_anc = reinterpret_cast<int32_t *>(take(r.trace_anc != nullptr, ((size_t)q.T * q.N + 1) / 2));
+        d.rec_u = reinterpret_cast<uint32_t *>(take(r.rec_u != nullptr, ((size_t)q.T * q.N + 1) / 2));
+        d.rec_z = take(r.rec_z != nullptr, (size_t)q.T * q.N);
+        d.rec_z0 = take(r.rec_z0 != nullptr, q.N);
         d.step_ctr = nullptr;
         d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
                               : nullptr;
@@ -666,6 +684,10 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         fetch(r.trace_ll, d.trace_ll, (size_t)q.T + 1);
         if (r.trace_anc && d.trace_anc)
             std::memcpy(r.trace_anc, host_of(reinterpret_cast<const double *>(d.trace_anc)), (size_t)q.T * q.N * 4);
+        if (r.rec_u && d.rec_u)
+            std::memcpy(r.rec_u, host_of(reinterpret_cast<const double *>(d.rec_u)), (size_t)q.T * q.N * 4);
+        fetch(r.rec_z, d.rec_z, (size_t)q.T * q.N);
+        fetch(r.rec_z0, d.rec_z0, q.N);
         r.status = PFG_OK;
     }
     return PFG_OK;

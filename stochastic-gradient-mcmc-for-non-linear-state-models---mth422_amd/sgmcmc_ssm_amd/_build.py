@@ -45,8 +45,8 @@ def is_stale():
 
 
 def _compile(args):
-    hipcc, src, obj, verbose = args
-    cmd = [hipcc] + FLAGS + _contract(src) + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+    hipcc, src, obj, verbose, extra = args
+    cmd = [hipcc] + FLAGS + _contract(src) + extra + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -55,28 +55,35 @@ def _compile(args):
     return obj
 
 
-def build_library(force=False, verbose=False, jobs=None):
+def build_library(force=False, verbose=False, jobs=None, tag=None, extra_flags=()):
     """Compile csrc/*.hip -> csrc/libpfgrad.so for gfx950.  -ffp-contract=off keeps the f64
-    instantiation on the reference's NumPy operation order (see csrc/pfg_device.hpp)."""
-    if not force and not is_stale():
+    instantiation on the reference's NumPy operation order (see csrc/pfg_device.hpp).
+    tag + extra_flags: a diagnostic build csrc/libpfgrad_<tag>.so (e.g. tag='stamps',
+    extra_flags=['-DPFG_PHASE_STAMPS']), selected at run time with PFGRAD_LIB=<path>."""
+    lib_path = LIB_PATH if tag is None else os.path.join(CSRC, "libpfgrad_{0}.so".format(tag))
+    if tag is None and not force and not is_stale():
         return LIB_PATH
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build" if tag is None else "build_" + tag)
     os.makedirs(objdir, exist_ok=True)
-    work = [(hipcc, os.path.join(CSRC, s), os.path.join(objdir, os.path.splitext(s)[0] + ".o"), verbose)
+    work = [(hipcc, os.path.join(CSRC, s), os.path.join(objdir, os.path.splitext(s)[0] + ".o"), verbose, list(extra_flags))
             for s in SOURCES]
     jobs = jobs or int(os.environ.get("PFGRAD_BUILD_JOBS", "0")) or min(len(work), os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(_compile, work))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1:       # python -m sgmcmc_ssm_amd._build <tag> <flags...>: diagnostic build
+        print(build_library(force=True, verbose=True, tag=sys.argv[1], extra_flags=sys.argv[2:]))
+    else:
+        print(build_library(force=True, verbose=True))

@@ -17,7 +17,7 @@ STAT = {"score": 0, "suff": 1, "none": 2, "predictive": 3}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
-MAX_STAT, MAX_THETA, OUT_DOUBLES, MAX_PRED = 4, 4, 8, 16
+MAX_STAT, MAX_THETA, OUT_DOUBLES, MAX_PRED, STAMP_WORDS = 4, 4, 8, 16, 16
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
 THETA_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
@@ -53,6 +53,7 @@ class Result(C.Structure):
         ("status", C.c_int32), ("reserved", C.c_int32),
         ("trace_anc", C.POINTER(C.c_int32)),
         ("pred", C.c_double * MAX_PRED),
+        ("rec_u", C.POINTER(C.c_uint32)), ("rec_z", _dp), ("rec_z0", _dp),
     ]
 
 
@@ -82,11 +83,14 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("trace_anc", "u8"),
     ("pred_z", "u8"), ("pred_out", "u8"), ("pred_scratch", "u8"),
     ("num_steps_ahead", "i4"), ("reserved3", "i4"),
+    ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"),
+    ("stamps", "u8"),
 ], align=True)
 
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
-           "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device")
+           "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
+           "pfg_last_variant")
 
 _lib = None
 
@@ -152,6 +156,8 @@ def load_library():
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
     lib.pfg_variant_name.restype = C.c_char_p
+    lib.pfg_last_variant.argtypes = [C.c_void_p]
+    lib.pfg_last_variant.restype = C.c_char_p
     lib.pfg_synchronize.argtypes = [C.c_void_p]
     lib.pfg_synchronize.restype = C.c_int
     lib.pfg_sgld_update_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -216,7 +222,7 @@ class Context:
             raise PfgError(rc, msg)
 
     # ---- host-buffer path ----------------------------------------------------------------
-    def run_batch(self, problems, want_final=False, want_trace=False):
+    def run_batch(self, problems, want_final=False, want_trace=False, want_draws=False):
         """problems: list of dicts with keys
              model, kernel, smoother, stat, dtype, rng (strings), N, T (implied by y), t1, tL,
              lambduh, prior_mean, prior_var, flags, y, weights, theta, z0,u,z | seed,stream,
@@ -297,6 +303,13 @@ class Context:
                 if not is_filter:
                     o["all_statistics"] = np.zeros((T + 1, N, h))
                     r.trace_stats = _ptr(o["all_statistics"])
+                if want_draws:
+                    # test instrumentation: the DEVICE generator's draws of this very launch
+                    o["rec_u"] = np.zeros((T, N), dtype=np.uint32)
+                    o["rec_z"] = np.zeros((T, N))
+                    o["rec_z0"] = np.zeros(N)
+                    r.rec_u = o["rec_u"].ctypes.data_as(C.POINTER(C.c_uint32))
+                    r.rec_z, r.rec_z0 = _ptr(o["rec_z"]), _ptr(o["rec_z0"])
             outs.append(o)
         self._check(self.lib.pfg_run_batch(self.handle, B, ps, rs))
         for b, o in enumerate(outs):
@@ -366,6 +379,10 @@ class Context:
 
     def variant_name(self, model, kernel, dtype, rng, n_max):
         return self.lib.pfg_variant_name(MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max)).decode()
+
+    def last_variant(self):
+        """Tag of the kernel variant the latest launch through this context ran."""
+        return self.lib.pfg_last_variant(self.handle).decode()
 
     def synchronize(self):
         self._check(self.lib.pfg_synchronize(self.handle))

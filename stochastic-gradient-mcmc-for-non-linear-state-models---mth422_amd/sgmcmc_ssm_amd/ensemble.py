@@ -420,6 +420,28 @@ class ChainEnsemble(object):
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    # -- measurement hooks ---------------------------------------------------------------------
+    def enable_stamps(self):
+        """Point every descriptor at a [C, 16] uint64 stamp record (pfg_dev_problem.stamps): the PF
+        kernel's wave 0 then writes s_memtime / s_memrealtime at its start and end (two scalar
+        instructions outside the T-loop)."""
+        self.stamps_dev = torch.zeros((self.C, _capi.STAMP_WORDS), dtype=torch.int64, device=self.device)
+        self._desc["stamps"] = self.stamps_dev.data_ptr() + np.arange(self.C, dtype=np.uint64) * np.uint64(8 * _capi.STAMP_WORDS)
+        self.desc_dev.copy_(torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)))
+        self.synchronize()
+
+    def kernel_clock(self):
+        """From the stamps of the latest PF launch: (median in-kernel shader clock in GHz, median
+        workgroup lifetime in shader cycles, per-phase cycle sums [10] or None).  The phase sums are
+        filled by diagnostic builds only (-DPFG_PHASE_STAMPS)."""
+        st = self.stamps_dev.cpu().numpy().astype(np.uint64)
+        cyc = (st[:, 2] - st[:, 0]).astype(np.float64)
+        real = (st[:, 3] - st[:, 1]).astype(np.float64)          # 100 MHz ticks
+        ok = real > 0
+        ghz = float(np.median(cyc[ok] / real[ok] * 0.1)) if ok.any() else float("nan")
+        phases = st[:, 4:14].sum(axis=0).astype(np.float64)
+        return ghz, float(np.median(cyc[ok])) if ok.any() else float("nan"), (phases if phases.sum() > 0 else None)
+
     # ------------------------------------------------------------------------------------
     def theta(self):
         """Current raw parameters of all chains, ndarray [C, P] (synchronises)."""

@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld,eurus}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -644,8 +644,61 @@ def make_ksd_fixtures():
     np.savez_compressed(os.path.join(HERE, "ksd.npz"), **out)
 
 
+def make_eurus_fixtures():
+    """BASELINE config 5 on its own data: data/EURUS_processed.npz (numeric / datetime64 arrays, loaded
+    without pickle), hourly log returns x 1000 split on gaps > 6 h exactly as
+    demo/exchange_rate/exchange_rate_full_demo.py:16-45 does (49 segments), SeqSVMSampler with the
+    settings of save_svm_params.py:60-66 (N = 10000, S = 16, B = 4, num_sequences = 1, epsilon = 0.001).
+    The fixture holds the segment data and the reference's outputs."""
+    d = np.load("/root/reference/data/EURUS_processed.npz")
+    observations = d["hourly_log_returns"].reshape(-1, 1) * 1000
+    dates = d["hourly_date"]
+    gap_indices = np.where(np.diff(dates) > np.timedelta64(6, "h"))[0].tolist()
+    split = []
+    for start, end in zip([0] + gap_indices, gap_indices + [observations.size]):
+        if end - start > 6:
+            split.append(observations[start:end])
+    out = {"segments": np.concatenate([o.reshape(-1) for o in split]),
+           "segment_lengths": np.array([len(o) for o in split], dtype=np.int64)}
+    np.random.seed(12345)
+    sampler = SeqSVMSampler(n=1, m=1, observations=split)
+    sampler.prior_init()
+    sampler.project_parameters()
+    out["theta0"] = theta_of("svm", sampler.parameters)
+    pfkw = dict(kind="pf", pf="poyiadjis_N", N=10000, subsequence_length=16, buffer_length=4, num_sequences=1)
+    np.random.seed(7)
+    out["noisy_gradient"] = as_vec("svm", sampler.noisy_gradient(**pfkw))
+    np.random.seed(8)
+    traj = [theta_of("svm", sampler.parameters)]
+    for _ in range(4):
+        sampler.sample_sgld(epsilon=0.001, **pfkw)
+        sampler.project_parameters()
+        traj.append(theta_of("svm", sampler.parameters))
+    out["sgld_traj"] = np.array(traj)
+    sampler = SeqSVMSampler(n=1, m=1, observations=split, parameters=SVMParameters(
+        A=np.eye(1) * out["theta0"][0], LQinv=np.eye(1) * out["theta0"][1], LRinv=np.eye(1) * out["theta0"][2]))
+    np.random.seed(9)
+    plist = sampler.fit(iter_type="SGLD", num_iters=3, output_all=True, epsilon=0.001, subsequence_length=16,
+                        num_sequences=1, buffer_length=4, kind="pf", pf_kwargs=dict(pf="poyiadjis_N", N=10000))
+    out["fit_SGLD"] = np.array([theta_of("svm", q) for q in plist])
+    # all sequences, whole-sequence windows (the "LD" setting of the demo with the O(N) filter), first 5 segments
+    sampler5 = SeqSVMSampler(n=1, m=1, observations=split[:5], parameters=plist[0].copy())
+    np.random.seed(10)
+    out["grad_all5"] = as_vec("svm", sampler5.noisy_gradient(kind="pf", pf="poyiadjis_N", N=1000, subsequence_length=-1,
+                                                             buffer_length=0, num_sequences=-1))
+    np.random.seed(11)
+    out["loglike_all5"] = np.float64(sampler5.noisy_loglikelihood(kind="pf", pf="poyiadjis_N", N=1000,
+                                                                  subsequence_length=-1, buffer_length=0,
+                                                                  num_sequences=-1))
+    print("EURUS:", len(split), "segments, lengths", out["segment_lengths"].min(), "..", out["segment_lengths"].max(),
+          "theta0", out["theta0"], "grad", out["noisy_gradient"])
+    np.savez_compressed(os.path.join(HERE, "eurus.npz"), **out)
+
+
 if __name__ == "__main__":
-    only = os.environ.get("GOLDEN_ONLY", "")        # e.g. GOLDEN_ONLY=ksd regenerates one file
+    only = os.environ.get("GOLDEN_ONLY", "")
+    if only in ("", "eurus"):
+        make_eurus_fixtures()        # e.g. GOLDEN_ONLY=ksd regenerates one file
     if only in ("", "pf"):
         make_pf_fixtures()
     if only in ("", "host"):

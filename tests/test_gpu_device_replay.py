@@ -1,0 +1,166 @@
+"""Deterministic parity of the DEVICE-generator kernels -- the instantiations bench.py times.
+
+The REPLAY kernels are pinned to the reference through NumPy's legacy stream; the device-generator
+kernels live in other translation units (-ffp-contract=fast -DPFG_FAST_ALGEBRA: fused multiply-adds,
+a cubic expm1, a 32-bit fixed-point resampling CDF in thread-major order searched with the raw
+generator word, Gaussian draws from the f32 transcendental units), so REPLAY parity says nothing
+about them.  Here the SAME instantiation (same template arguments, same code object) additionally
+writes out the random inputs it consumed -- per step and child the 32-bit word it searched the CDF
+with and its standard normal, plus the x0 normals (pfg_result.rec_u / rec_z / rec_z0) -- and the
+CPU oracle replays the launch on those numbers: `po.pf_window` (the reference's T-loop, pinned to
+the reference by tests/test_oracle_golden.py) with its resampling step replaced by
+`po.device_ancestors` (the kernels' CDF layout).  Everything downstream of the random inputs is
+deterministic, so trajectories, ancestors, statistics, log-likelihood and gradient must agree.
+
+Tolerance: rtol 1e-8 (fused multiply-adds ~1e-16, cubic expm1 < 3e-12 relative, parallel prefix
+sums).  An ancestor flips only if a 32-bit word lands within ~3e-12 * 2^32 of a CDF entry:
+probability ~1e-5 per 1e6 draws; asserted exactly.
+"""
+import numpy as np
+import pytest
+
+from oracle import pf_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-8, 1e-8
+
+THETA = {
+    "svm": np.array([0.95, 0.5 ** -0.5, 0.5 ** -0.5]),
+    "lgssm": np.array([0.9, 1.0, 0.7 ** -0.5, 1.0]),
+    "garch": None,      # filled below from (alpha, beta, gamma) = (.1, .8, .05), R = .3
+}
+
+
+def _garch_theta():
+    alpha, beta, gamma, R = 0.1, 0.8, 0.05, 0.3
+    phi = beta + gamma
+    lam = beta / phi
+    mu = alpha / (1.0 - phi)
+    logit = lambda p: np.log(p / (1.0 - p))
+    return np.array([np.log(mu), logit(phi), logit(lam), R ** -0.5])
+
+
+THETA["garch"] = _garch_theta()
+
+
+def _series(model, T, seed):
+    """Synthetic observations of roughly the model's scale (parity does not need model-exact data)."""
+    rs = np.random.RandomState(seed)
+    if model == "svm":
+        x = np.zeros(T)
+        for t in range(1, T):
+            x[t] = 0.95 * x[t - 1] + np.sqrt(0.5) * rs.normal()
+        return np.exp(x / 2) * np.sqrt(0.5) * rs.normal(size=T)
+    if model == "lgssm":
+        x = np.zeros(T)
+        for t in range(1, T):
+            x[t] = 0.9 * x[t - 1] + np.sqrt(0.7) * rs.normal()
+        return x + rs.normal(size=T)
+    return 0.8 * rs.normal(size=T)
+
+
+# model, kernel, pf, lambduh, N, T, (t1, tL, weights?), forced variant, (NT, PPT, cdf)
+CASES = [
+    # BASELINE configs[1] = the bench workload, on the bench instantiation pf_reg_kernel<0,0,double,256,4,1,false,0>
+    ("svm", "prior", "poyiadjis_N", 1.0, 1000, 1000, None, "wg256x4s", (256, 4, "fixed32")),
+    ("svm", "prior", "nemeth", 0.95, 1000, 120, (10, 100, True), "wg256x4s", (256, 4, "fixed32")),
+    ("svm", "prior", "filter", 1.0, 777, 60, None, "wg256x4s", (256, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 1000, 200, None, "wg1024x1", (1024, 1, "fixed32")),   # one chain alone
+    ("svm", "prior", "poyiadjis_N", 1.0, 900, 80, None, "wg256x4", (256, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 200, 100, None, "wg256x1", (256, 1, "fixed32")),
+    # config 1: LGSSM T=200 N=100 (one wave per window)
+    ("lgssm", "optimal", "poyiadjis_N", 1.0, 100, 200, None, "wg64x2", (64, 2, "fixed32")),
+    ("lgssm", "prior", "nemeth", 0.9, 128, 50, None, "wg64x2", (64, 2, "fixed32")),
+    # config 3: GARCH N=1000, S=16 B=4 window
+    ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
+    ("garch", "prior", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
+    # config 4: SVM N=4000, LDS-resident 1024 x 4
+    ("svm", "prior", "poyiadjis_N", 1.0, 4000, 250, None, "wg1024x4s", (1024, 4, "fixed32")),
+    # config 5: SVM N=10000, S=16 B=4 window, large-N kernel (fp64 CDF)
+    ("svm", "prior", "poyiadjis_N", 1.0, 10000, 24, (4, 20, True), "big16384", (1024, 16, "f64")),
+    ("garch", "optimal", "poyiadjis_N", 1.0, 4000, 40, None, "big4096", (1024, 4, "f64")),
+    ("lgssm", "optimal", "nemeth", 0.95, 3000, 40, None, "big4096", (1024, 4, "f64")),
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sgmcmc_ssm_amd import _capi
+    return _capi.default_context(0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "{0}-{1}-{2}-N{4}-T{5}-{7}".format(*c))
+def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
+    model, kernel, pf, lam, N, T, window, variant, (NT, PPT, cdf) = case
+    theta = THETA[model]
+    y = _series(model, T, seed=N + T)
+    t1, tL, weights = 0, T, None
+    if window is not None:
+        t1, tL = window[0], window[1]
+        weights = np.linspace(20.0, 30.0, tL - t1) if window[2] else None
+    if model == "garch":
+        pm, pv = po.garch_prior_x(theta)
+        pv = float(np.asarray(pv).reshape(-1)[0])
+    else:
+        pm, pv = 0.0, 10.0
+    smoother = "filter" if pf == "filter" else "nemeth"
+    q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="device", N=N,
+             t1=t1, tL=tL, lambduh=lam, prior_mean=pm, prior_var=pv, y=y, weights=weights, theta=theta,
+             seed=20241004 + N, stream=T)
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+    assert ctx.last_variant() == variant          # the instantiation under test really ran
+
+    words, z, z0 = o["rec_u"], o["rec_z"], o["rec_z0"]
+    assert np.all(np.isfinite(z)) and np.all(np.isfinite(z0)) and np.any(words != 0)
+    ref = po.pf_window(model, theta, y, N, z0, None, z, kernel=kernel, pf=pf, lambduh=lam, stat="score",
+                       t1=t1, tL=tL, weights=weights, prior_mean=pm, prior_var=pv, save_all=True,
+                       resampler=lambda t, logw: po.device_ancestors(logw, words[t], NT, PPT, cdf))
+
+    flips = int(np.sum(o["all_ancestors"] != ref["all_ancestors"]))
+    assert flips == 0, "{0} ancestor indices differ".format(flips)
+    np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["all_log_weights"], ref["all_log_weights"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["all_loglikelihood_estimate"], ref["all_loglikelihood_estimate"], rtol=RTOL, atol=ATOL)
+    if pf != "filter":
+        np.testing.assert_allclose(o["all_statistics"], ref["all_statistics"], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-7)
+        # the north-star bar, on the timed kernel: gradient L2 error < 1e-4
+        assert np.linalg.norm(o["mean_stat"] - ref["mean_statistic"]) < 1e-6 * max(1.0, np.linalg.norm(ref["mean_statistic"]))
+    else:
+        np.testing.assert_allclose(o["mean_stat"], ref["statistics"], rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(o["loglik"], ref["loglikelihood_estimate"], rtol=RTOL, atol=ATOL)
+
+
+def test_recording_does_not_change_the_launch(ctx, monkeypatch):
+    """The recorded launch is the timed launch: with and without the record / trace buffers the
+    same (seed, stream) gives bitwise the same result."""
+    monkeypatch.setenv("PFGRAD_VARIANT", "wg256x4s")
+    y = _series("svm", 300, seed=5)
+    q = dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="device", N=1000,
+             t1=0, tL=300, lambduh=1.0, prior_mean=0.0, prior_var=10.0, y=y, theta=THETA["svm"], seed=11, stream=3)
+    a = ctx.run_batch([dict(q)])[0]
+    b = ctx.run_batch([dict(q)], want_trace=True, want_draws=True)[0]
+    assert np.array_equal(a["mean_stat"], b["mean_stat"]) and a["loglik"] == b["loglik"]
+
+
+def test_recorded_draws_are_standard(ctx, monkeypatch):
+    """The recorded inputs themselves: 1e6 normals (f32-unit Box-Muller) and 1e6 32-bit words."""
+    from scipy import stats
+    monkeypatch.setenv("PFGRAD_VARIANT", "wg256x4s")
+    T, N = 1000, 1000
+    y = _series("svm", T, seed=9)
+    q = dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="device", N=N,
+             t1=0, tL=T, lambduh=1.0, prior_mean=0.0, prior_var=10.0, y=y, theta=THETA["svm"], seed=99, stream=1)
+    o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+    z = o["rec_z"].reshape(-1)
+    u = (o["rec_u"].reshape(-1).astype(np.float64) + 0.5) / 2.0 ** 32
+    n = z.shape[0]
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1.0) < 5 * np.sqrt(2.0 / n)
+    assert abs(np.mean(z ** 4) - 3.0) < 5 * np.sqrt(96.0 / n)
+    assert stats.kstest(z, "norm").pvalue > 1e-4
+    assert stats.kstest(u, "uniform").pvalue > 1e-4
+    # no serial structure between a child's word and its normal, or along the particle axis
+    assert abs(np.corrcoef(u, z)[0, 1]) < 5 / np.sqrt(n)
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5 / np.sqrt(n)

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void stream_kernel(int iters, double *out, uns
     const float b32 = 1.0001f, c32 = 1e-6f;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) { a64[j] = threadIdx.x + j; a32[j] = threadIdx.x + j; u32[j] = threadIdx.x * 7 + j; }
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -41,11 +42,15 @@ __global__ __launch_bounds__(256) void stream_kernel(int iters, double *out, uns
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) s += a64[j] + (double)a32[j] + (double)u32[j];
     if (s == 123.456) out[0] = s;
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+        cyc[gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0;     // 100 MHz ticks
+    }
 }
 
 template <int KIND>
@@ -57,7 +62,7 @@ void run(const char *name, int blocks_per_cu, int iters) {
     const int grid = cus * blocks_per_cu;
     const size_t lds = (size_t)(160 * 1024 / blocks_per_cu) - 1024;     // pins blocks_per_cu workgroups per CU
     double *out; unsigned long long *cyc;
-    CK(hipMalloc(&out, 8)); CK(hipMalloc(&cyc, (size_t)grid * 4 * 8));
+    CK(hipMalloc(&out, 8)); CK(hipMalloc(&cyc, (size_t)grid * 8 * 8));
     auto k = stream_kernel<KIND>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -68,18 +73,21 @@ void run(const char *name, int blocks_per_cu, int iters) {
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h((size_t)grid * 4);
+    std::vector<unsigned long long> h((size_t)grid * 4), hr((size_t)grid * 4);
     CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hr.data(), cyc + (size_t)grid * 4, hr.size() * 8, hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
+    std::sort(hr.begin(), hr.end());
     const double med = (double)h[h.size() / 2];
+    const double ghz = med / (double)hr[hr.size() / 2] * 0.1;     // shader cycles per 100 MHz tick
     const double inst_per_wave = (double)iters * UNROLL;
     // waves per SIMD = blocks_per_cu (256 threads = 4 waves = one per SIMD)
     const double cyc_per_inst_simd = med / (inst_per_wave * blocks_per_cu);
     const double total_inst = inst_per_wave * 4.0 * grid;
     printf("%-14s waves/SIMD %d  grid %5d  %8.3f ms  wave-cycles(median, s_memtime) %.3e  => %.2f SIMD-cycles per wave-instruction"
-           "  [events: %.2f at 2.4 GHz]  wave-instructions %.4e\n",
+           "  in-kernel clock %.3f GHz (loop %.3f ms)  wave-instructions %.4e\n",
            name, blocks_per_cu, grid, ms, med, cyc_per_inst_simd,
-           ms * 1e-3 * 2.4e9 * cus * 4 / total_inst, total_inst);
+           ghz, med / ghz * 1e-6, total_inst);
     CK(hipFree(out)); CK(hipFree(cyc));
 }
 
