@@ -1,25 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- SGLD steps/sec of the particle-filter gradient path on MI355X.
 
-Workload (BASELINE.json configs[1]): SVM synthetic series, T=1000, N=1000 particles,
-SGLD on the full sequence (S=-1), pf='poyiadjis_N', bootstrap kernel, epsilon=0.1,
-prior variance 100 (nonlinear_ssm_pf_experiment_scripts/svm/{demo_setup.py:65-79,driver.py:54}).
+Default workload = BASELINE.json configs[1] (the config the metric is quoted on): SVM synthetic
+series, T=1000, N=1000 particles, SGLD on the full sequence (S=-1), pf='poyiadjis_N', bootstrap
+kernel, epsilon=0.1, prior variance 100 (nonlinear_ssm_pf_experiment_scripts/svm/
+{demo_setup.py:65-79,driver.py:54}).  `--config c1|c3|c4|c5` runs the other BASELINE configs
+(parity-test cases with their own profiles; never the headline line).
 
 One bench "step" = one SGLD step (sample_sgld + project_parameters, what evaluator.py:343-347
-times) of EVERY chain on the GPU: one particle-filter launch (one workgroup per chain, the
-whole T-loop inside) + one update launch.  `value` = chain-steps per second summed over all
-GPUs (chains are independent; weak scaling: --chains-per-gpu is fixed as N grows).
-Everything is resident in HBM when the timed region starts.
+times) of EVERY chain on the GPU: one particle-filter launch (one workgroup per chain, the whole
+T-loop inside) + one update launch.  `value` = chain-steps per second summed over all GPUs (chains
+are independent; weak scaling: --chains-per-gpu is fixed as N grows).  Everything is resident in
+HBM when the timed region starts.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(python -m torch.distributed.run, one per GPU) BEFORE anything in this process touches the GPU,
+and exits with their status.
 
 The JSON line also carries
-  roofline      algorithmic bytes/launch (2*(n+1+h)*8 B per particle-timestep,
-                fp64) / mean PF-kernel duration (HIP events on the launch stream), vs 8 TB/s
+  roofline      the binding resource of the dominant kernel.  The LDS-resident kernels stream no
+                particle state through HBM, so the bound is VALU issue: achieved = (per-class VALU
+                instruction counts of the launch, committed rocprofv3 PMC passes) x (issue cycles per
+                class, measured on this GPU with tools/calib/valu_calib) / live kernel time; peak =
+                1024 SIMDs x the in-kernel shader clock (s_memtime / s_memrealtime stamps of the
+                timed launches).  The SURVEY 8(d) HBM model (2*(n+1+h)*8 B per particle-timestep)
+                is kept as `hbm_model`, explicitly non-binding.  The large-N kernel (c5) does stream
+                its state: there bound = "hbm" and the algorithmic bytes are real traffic.
   cpu_baseline  the CPU oracle (NumPy restatement of the reference, bit-identical to it) timed
                 on this box's host, 1 core, on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,14 +47,31 @@ import numpy as np  # noqa: E402
 
 T_SERIES, N_PART = 1000, 1000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 1024             # 256 CUs x 4 SIMDs
+
+RNG_PRECISION = ("device generator: xoshiro128++ per lane keyed by Philox4x32-10(seed; lane, global chain id, step); "
+                 "32-bit uniforms searched against a 32-bit fixed-point CDF (LDS-resident kernels) or an fp64 CDF "
+                 "(large-N kernel); Box-Muller normals evaluated on the f32 transcendental units (v_log/v_sin/v_cos) "
+                 "and widened to f64; all arithmetic on the particle state, weights, CDF sums and statistics is fp64")
+
+CONFIGS = {
+    # name: (model, T_series, N, S, B, chains/GPU, description)
+    "c1": ("lgssm", 200, 100, -1, -1, 2048, "LGSSM d=1 synthetic T=200 N=100, SGLD full sequence, optimal kernel (BASELINE configs[0])"),
+    "c2": ("svm", 1000, 1000, -1, -1, 3072, "SVM synthetic T=1000 N=1000, SGLD full sequence (S=-1), poyiadjis_N, prior kernel (BASELINE configs[1])"),
+    "c3": ("garch", 1000, 1000, 16, 4, 4096, "GARCH synthetic T=1000 N=1000, SGLD buffered PF S=16 B=4, poyiadjis_N, optimal kernel (BASELINE configs[2])"),
+    "c4": ("svm", 1000, 4000, -1, -1, 256, "SVM synthetic T=1000 N=4000, SGLD full sequence, poyiadjis_N (BASELINE configs[3], saturating variant)"),
+    "c5": ("svm", None, 10000, 16, 4, 512, "EURUS hourly log returns x1000, 49 gap-split segments, SeqSVM N=10000 S=16 B=4 num_sequences=1 (BASELINE configs[4])"),
+}
+STATE_STAT = {"svm": (1, 3), "garch": (2, 4), "lgssm": (1, 4)}
 
 
-def make_workload(model):
+def make_workload(model, T=T_SERIES):
+    """(parameters, observations, prior, settings) of one model's synthetic workload."""
     if model == "svm":
         from sgmcmc_ssm_amd.models.svm import SVMParameters, SVMPrior, generate_svm_data
         p = SVMParameters(A=np.eye(1) * 0.95, Q=np.eye(1) * 0.5, R=np.eye(1) * 0.5)
         np.random.seed(12345)
-        data = generate_svm_data(T=T_SERIES, parameters=p)
+        data = generate_svm_data(T=T, parameters=p)
         prior = SVMPrior.generate_default_prior(var=100.0, n=1, m=1)
         return p, data["observations"], prior, dict(epsilon=0.1, S=-1, B=-1, kernel="prior", n=1, h=3)
     if model == "garch":
@@ -48,17 +79,55 @@ def make_workload(model):
         lm, lp, ll = GARCHParameters.convert_alpha_beta_gamma(0.1, 0.8, 0.05)
         p = GARCHParameters(log_mu=lm, logit_phi=lp, logit_lambduh=ll, LRinv=np.eye(1) * 0.3 ** -0.5)
         np.random.seed(222)
-        data = generate_garch_data(T=T_SERIES, parameters=p)
+        data = generate_garch_data(T=T, parameters=p)
         prior = GARCHPrior.generate_default_prior(var=1.0, n=1, m=1)
         return p, data["observations"], prior, dict(epsilon=0.01, S=16, B=4, kernel="optimal", n=2, h=4)
+    if model == "lgssm":
+        from sgmcmc_ssm_amd.models.lgssm import LGSSMParameters, LGSSMPrior, generate_lgssm_data
+        p = LGSSMParameters(A=np.eye(1) * 0.9, C=np.eye(1), Q=np.eye(1) * 0.7, R=np.eye(1))
+        np.random.seed(333)
+        data = generate_lgssm_data(T=T, parameters=p)
+        prior = LGSSMPrior.generate_default_prior(var=100.0, n=1, m=1)
+        return p, data["observations"], prior, dict(epsilon=0.1, S=-1, B=-1, kernel="optimal", n=1, h=4)
     raise ValueError(model)
+
+
+def config_workload(name):
+    """One BASELINE config -> dict(model, p0, y (array or list of segments), prior, S, B, kernel, epsilon, N, ...)."""
+    model, T, N, S, B, chains, desc = CONFIGS[name]
+    if name == "c5":
+        from sgmcmc_ssm_amd.models.svm import SVMParameters, SVMPrior
+        path = os.path.join(ROOT, "tests", "golden", "eurus.npz")
+        data_kind = "EURUS_processed.npz segments (fixture tests/golden/eurus.npz: data arrays of the reference's demo)"
+        if os.path.exists(path):
+            g = np.load(path)
+            lens = g["segment_lengths"]
+            flat = g["segments"]
+            th = g["theta0"]
+        else:   # same shape, synthetic values
+            rs = np.random.RandomState(5)
+            lens = rs.randint(48, 127, size=49)
+            flat = rs.normal(size=int(lens.sum())) * 0.8
+            th = np.array([0.9999, 1.6, 1.5])
+            data_kind = "synthetic segments of the EURUS shape (fixture missing)"
+        bounds = np.concatenate([[0], np.cumsum(lens)])
+        y = [flat[bounds[k]:bounds[k + 1]].reshape(-1, 1) for k in range(len(lens))]
+        p = SVMParameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+        prior = SVMPrior.generate_default_prior(var=100.0, n=1, m=1)
+        return dict(name=name, model="svm", p0=p, y=y, prior=prior, S=S, B=B, kernel="prior", epsilon=0.001, N=N,
+                    chains=chains, desc=desc, window_T=S + 2 * B, data=data_kind, T_series=int(lens.sum()))
+    p, y, prior, cfg = make_workload(model, T)
+    return dict(name=name, model=model, p0=p, y=y, prior=prior, S=S, B=B, kernel=cfg["kernel"], epsilon=cfg["epsilon"],
+                N=N, chains=chains, desc=desc, window_T=(T if S == -1 else S + 2 * B), data="synthetic", T_series=T)
 
 
 def grad_error_vs_reference():
     """The second half of BASELINE.json's metric: gradient L2 error vs the reference on identical
     seeds.  Runs the HIP path (REPLAY generator, fp64) on the reference's own known-answer case
     committed under tests/golden (SVM T=1000 N=1000, np.random.seed(99): the SURVEY 8c vector,
-    produced by the reference itself) and returns the errors.  No oracle involved."""
+    produced by the reference itself) and returns the errors.  No oracle involved.  NB this pins the
+    REPLAY instantiation; the timed device-generator instantiation is pinned by
+    tests/test_gpu_device_replay.py (the oracle replays the launch's own recorded draws)."""
     from sgmcmc_ssm_amd import _capi
     path = os.path.join(ROOT, "tests", "golden", "pf_window.npz")
     if not os.path.exists(path):
@@ -77,10 +146,13 @@ def grad_error_vs_reference():
              theta=g["w0/theta"], z0=z0, u=u, z=z)
     o = _capi.default_context(torch_device_index()).run_batch([q])[0]
     ref = g["w0/mean_statistic"]
-    return {"grad_l2_err_vs_ref": float(np.linalg.norm(o["mean_stat"] - ref)),
+    return {"kernel": "REPLAY instantiation (reference operation order, fp64 CDF, host MT19937 streams)",
+            "grad_l2_err_vs_ref": float(np.linalg.norm(o["mean_stat"] - ref)),
             "grad_l2_ref_norm": float(np.linalg.norm(ref)),
             "loglik_abs_err_vs_ref": float(abs(o["loglik"] - float(g["w0/loglikelihood_estimate"]))),
-            "case": "SVM T=1000 N=1000, np.random.seed(99), reference fixture tests/golden/pf_window.npz:w0, REPLAY fp64"}
+            "case": "SVM T=1000 N=1000, np.random.seed(99), reference fixture tests/golden/pf_window.npz:w0, REPLAY fp64",
+            "timed_kernel_parity": "tests/test_gpu_device_replay.py: the timed device-generator instantiation records its "
+                                   "draws and the CPU oracle replays the launch (rtol 1e-8, zero ancestor flips)"}
 
 
 def torch_device_index():
@@ -88,36 +160,40 @@ def torch_device_index():
     return torch.cuda.current_device()
 
 
-def cpu_baseline(model, p0, y, prior, cfg, budget_s=12.0):
+def cpu_baseline(w, budget_s=12.0):
     """Reference CPU path: SGLD steps/s of ONE chain with the NumPy oracle (bit-identical to the
     reference's arithmetic), single thread.  Bounded: >= 3 steps, about `budget_s` seconds."""
     from oracle import pf_oracle as po
     from sgmcmc_ssm_amd.sgmcmc_sampler import random_subsequence_and_weights
-    params = p0.copy()
-    T = y.shape[0]
-    eps = cfg["epsilon"]
-    names = po.SCORE_NAMES[model]
+    model, prior = w["model"], w["prior"]
+    params = w["p0"].copy()
+    segs = w["y"] if isinstance(w["y"], list) else [w["y"]]
+    T_total = sum(len(s) for s in segs)
+    eps = w["epsilon"]
     rng = np.random.RandomState(0)
 
     def one_step():
-        if cfg["S"] == -1:
-            lo, hi, t1, tL, w = 0, T, 0, T, None
+        y = segs[rng.randint(len(segs))] if len(segs) > 1 else segs[0]
+        T = y.shape[0]
+        if w["S"] == -1 or T - w["S"] <= 0:
+            lo, hi, t1, tL, wts = 0, T, 0, T, None
         else:
             np.random.seed(rng.randint(2 ** 31))
-            s, e, w = random_subsequence_and_weights(cfg["S"], T)
-            lo, hi = max(0, s - cfg["B"]), min(T, e + cfg["B"])
+            s, e, wts = random_subsequence_and_weights(w["S"], T)
+            lo, hi = max(0, s - w["B"]), min(T, e + w["B"])
             t1, tL = s - lo, e - lo
         if model == "garch":
             pm, pv = po.garch_prior_x(params.theta())
         else:
             pm, pv = 0.0, 10.0
-        g = po.pf_gradient_estimate(model, params.theta(), y[lo:hi], N_PART, rng=rng, kernel=cfg["kernel"],
-                                    pf="poyiadjis_N", t1=t1, tL=tL, weights=w, prior_mean=pm,
+        g = po.pf_gradient_estimate(model, params.theta(), y[lo:hi], w["N"], rng=rng, kernel=w["kernel"],
+                                    pf="poyiadjis_N", t1=t1, tL=tL, weights=wts, prior_mean=pm,
                                     prior_var=float(np.asarray(pv).reshape(-1)[0]))
         gp = prior.grad_logprior(params)
+        scale = T_total / float(T) if len(segs) > 1 else 1.0
         for var in params.var_dict:
-            delta = (gp[var] + g[var]) / T
-            noise = rng.normal(loc=0, scale=np.sqrt(1.0 / T), size=params.var_dict[var].shape)
+            delta = (gp[var] + scale * g[var]) / T_total
+            noise = rng.normal(loc=0, scale=np.sqrt(1.0 / T_total), size=params.var_dict[var].shape)
             params.var_dict[var] += eps * delta + np.sqrt(2.0 * eps) * noise
         params.project_parameters()
 
@@ -131,9 +207,145 @@ def cpu_baseline(model, p0, y, prior, cfg, budget_s=12.0):
             break
         if el > 3 * budget_s:
             break
+    cores = os.cpu_count() or 1
     return dict(value=n / el, unit="SGLD steps/s", cores=1, kind="port",
-                sample="{0} full SGLD steps of one chain ({1:.1f} s), NumPy oracle, 1 thread; "
-                       "host has {2} cores".format(n, el, os.cpu_count()))
+                all_cores_bound=n / el * cores,
+                sample="{0} full SGLD steps of one chain ({1:.1f} s), NumPy oracle, 1 thread; host has {2} cores; "
+                       "all_cores_bound = cores x single-core rate (one independent chain per core)".format(n, el, cores))
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline pieces
+# ------------------------------------------------------------------------------------------------
+def _load_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def valu_roofline(key, chains, kern_ms, clock_ghz):
+    """VALU-issue roofline of an LDS-resident launch: per-class instruction counts (committed PMC
+    passes, profiles/valu_issue.json, scaled to `chains`) x calibrated issue cycles per class
+    (profiles/valu_calibration.json, measured with tools/calib/valu_calib at 4 waves per SIMD)."""
+    rec = (_load_json("valu_issue.json") or {}).get(key)
+    cal = _load_json("valu_calibration.json")
+    if not rec or not cal or not (clock_ghz == clock_ghz):
+        return None
+    cost = cal["cycles_per_wave_instruction_at_4_waves_per_simd"]
+    scale = float(chains) / rec["chains"]
+    cls = rec["classes"]
+    f64 = (cls["ADD_F64"] + cls["MUL_F64"] + cls["FMA_F64"]) * scale
+    tr64 = cls["TRANS_F64"] * scale
+    tr32 = cls["TRANS_F32"] * scale
+    total = cls["VALU"] * scale
+    other = total - f64 - tr64 - tr32
+    cycles = f64 * cost["f64"] + tr64 * cost["trans_f64"] + tr32 * cost["trans_f32"] + other * cost["b32"]
+    achieved = cycles / (kern_ms * 1e-3) / 1e9             # G issue-cycles per second actually delivered
+    peak = N_SIMD * clock_ghz                               # G issue-cycles per second available
+    return dict(achieved=achieved, peak=peak, frac=achieved / peak,
+                valu_instructions_per_launch=total, fp64_arith_instructions_per_launch=f64,
+                issue_cycle_model=cost, counters_from="profiles/valu_issue.json:" + key,
+                in_kernel_clock_ghz=clock_ghz)
+
+
+def replay_arithmetic_leg(w, dev_index, C=768, reps=3):
+    """Throughput of the REPLAY-arithmetic kernel (reference operation order, fp64 CDF, -ffp-contract=off)
+    on device-resident pre-generated streams: the cost of parity-pinned arithmetic, on record."""
+    import torch
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    if w["S"] != -1 or isinstance(w["y"], list):
+        return None
+    ens = ChainEnsemble(w["model"], w["y"], w["p0"], num_chains=C, N=w["N"], pf="poyiadjis_N", kernel=w["kernel"],
+                        epsilon=w["epsilon"], prior=w["prior"], subsequence_length=-1, buffer_length=-1, seed=5,
+                        chain_offset=2 * 10 ** 6, device=dev_index)
+    T, N = ens.T, ens.N
+    dev = ens.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    z0 = torch.randn((C, N), dtype=torch.float64, device=dev, generator=gen)
+    u = torch.rand((C, T, N), dtype=torch.float64, device=dev, generator=gen)
+    z = torch.randn((C, T, N), dtype=torch.float64, device=dev, generator=gen)
+    d = ens._desc
+    idx = np.arange(C, dtype=np.uint64)
+    d["z0"] = z0.data_ptr() + idx * np.uint64(8 * N)
+    d["u"] = u.data_ptr() + idx * np.uint64(8 * T * N)
+    d["z"] = z.data_ptr() + idx * np.uint64(8 * T * N)
+    ens.desc_dev.copy_(torch.from_numpy(d.view(np.uint8).reshape(C, -1)))
+    st = torch.cuda.current_stream(dev)
+
+    def launch():
+        ens.ctx.launch_device(ens.model, ens.kernel, ens.dtype, "replay", N, C, ens.desc_dev.data_ptr(), st.cuda_stream)
+
+    launch()
+    torch.cuda.synchronize(dev)
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st); launch(); b.record(st)
+        torch.cuda.synchronize(dev)
+        ms.append(a.elapsed_time(b))
+    g, _ = ens.last_gradient_statistics()
+    if not np.all(np.isfinite(g)):
+        raise SystemExit("non-finite gradients in the replay-arithmetic leg")
+    k = float(np.median(ms))
+    return dict(value=C / (k * 1e-3), unit="SGLD steps/s (PF launch only)", chains=C, kernel_ms=k,
+                kernel_variant=ens.ctx.last_variant(),
+                note="REPLAY instantiation on device-resident pre-generated fp64 streams (torch generator; the host "
+                     "MT19937 stream of the drop-in path is excluded): the arithmetic the reference fixtures pin")
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-rank plumbing
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`--gpus n` without a launcher: start n ranks (one per GPU) as children of this process, which
+    has not touched the GPU, and return their exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def rank_epilogue(local_theta, elapsed, device=None):
+    """What every rank does after its timed steps: max of the elapsed time over ranks, gather of
+    the samples in global chain order.  Returns (elapsed_max, samples [world*C, P])."""
+    from sgmcmc_ssm_amd import distributed
+    elapsed = distributed.max_over_ranks(elapsed, device=device)
+    samples = distributed.gather_samples(local_theta)
+    return elapsed, samples
+
+
+def cpu_rehearsal(args):
+    """No GPU: the rank logic alone under gloo (spawn, chain ranges, barrier, max-over-ranks,
+    gather in global chain order) with ChainEnsemble-shaped [C, P] tensors."""
+    import torch
+    from sgmcmc_ssm_amd import distributed
+    rank, world, _ = distributed.init_from_env(backend="gloo")
+    C, P = args.chains_per_gpu or 8, 3
+    lo, hi = distributed.chain_range(rank, C)
+    theta = torch.arange(lo, hi, dtype=torch.float64).reshape(C, 1) * torch.ones((1, P), dtype=torch.float64)
+    distributed.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    elapsed, samples = rank_epilogue(theta, time.perf_counter() - t0)
+    ok = bool(torch.equal(samples[:, 0], torch.arange(world * C, dtype=torch.float64)))
+    if rank == 0:
+        print(json.dumps({"rehearsal": "cpu-gloo", "ranks": world, "n_gpus": 0, "chains_total": world * C,
+                          "gathered_in_global_chain_order": ok, "elapsed_max_s": elapsed}), flush=True)
+    distributed.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -141,37 +353,61 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains-per-gpu", type=int, default=3072)
-    ap.add_argument("--model", default="svm", choices=["svm", "garch"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--chains-per-gpu", type=int, default=0, help="0 = the config's default")
+    ap.add_argument("--model", default=None, choices=["svm", "garch"], help="(compat) svm = c2, garch = c3")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-chain", action="store_true",
-                    help="skip the one-chain-alone latency measurement (profiling runs: keeps every "
+                    help="skip the one-chain-alone latency, replay-arithmetic and parity legs (profiling runs: keeps every "
                          "launch of the PF kernel the same size, so rocprofv3's per-kernel average is the launch time)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow more ranks than GPUs (ranks fold onto devices; the line is labelled, n_gpus = distinct devices)")
+    ap.add_argument("--cpu-rehearsal", action="store_true", help="no GPU: exercise the multi-rank logic under gloo")
     args = ap.parse_args()
+    if args.model is not None:
+        args.config = {"svm": "c2", "garch": "c3"}[args.model]
+
+    # ---- launcher: nothing above or below this block has touched the GPU yet ---------------------
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        sys.exit(spawn_ranks(args.gpus))
+    if env_world > 0 and env_world != args.gpus:
+        raise SystemExit("--gpus {0} but WORLD_SIZE={1}".format(args.gpus, env_world))
 
     os.environ.setdefault("OMP_NUM_THREADS", "1")
+    if args.cpu_rehearsal:
+        sys.exit(cpu_rehearsal(args))
     import torch
-    from sgmcmc_ssm_amd import distributed, _capi
+    from sgmcmc_ssm_amd import distributed
     from sgmcmc_ssm_amd.ensemble import ChainEnsemble
 
-    rank, world, local_rank = distributed.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus {0} but WORLD_SIZE={1}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()     # 1:1 on a full node; folds ranks when rehearsing on one GPU
+    ndev = torch.cuda.device_count()
+    world_env = max(env_world, 1)
+    if world_env > ndev and not args.rehearsal:
+        raise SystemExit("--gpus {0} but only {1} GPU(s) visible: ranks would share devices "
+                         "(pass --rehearsal to fold them; the line is then labelled)".format(world_env, ndev))
+    rank, world, local_rank = distributed.init_from_env()
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    n_distinct = min(world, ndev)
 
-    p0, y, prior, cfg = make_workload(args.model)
-    C = args.chains_per_gpu
+    w = config_workload(args.config)
+    model = w["model"]
+    C = args.chains_per_gpu or w["chains"]
     lo, _ = distributed.chain_range(rank, C)
-    ens = ChainEnsemble(args.model, y, p0, num_chains=C, N=N_PART, pf="poyiadjis_N", kernel=cfg["kernel"],
-                        epsilon=cfg["epsilon"], prior=prior, subsequence_length=cfg["S"],
-                        buffer_length=cfg["B"], dtype=args.dtype, seed=2024, chain_offset=lo, device=dev_index)
 
+    def make_ensemble(chains, seed, offset):
+        return ChainEnsemble(model, w["y"], w["p0"], num_chains=chains, N=w["N"], pf="poyiadjis_N", kernel=w["kernel"],
+                             epsilon=w["epsilon"], prior=w["prior"], subsequence_length=w["S"], buffer_length=w["B"],
+                             dtype=args.dtype, seed=seed, chain_offset=offset, device=dev_index)
+
+    ens = make_ensemble(C, 2024, lo)
+    ens.enable_stamps()
     for _ in range(args.warmup):
         ens.step(1)
     torch.cuda.synchronize(dev)
@@ -195,63 +431,64 @@ def main():
     distributed.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    elapsed = distributed.max_over_ranks(elapsed, device=dev)
-
-    samples = ens.gather_samples()            # the one collective (RCCL all_gather), outside the timing
+    # the one collective (RCCL all_gather of the samples) + max over ranks, outside the timing
+    elapsed, samples = rank_epilogue(ens.theta_dev[:, :ens.P].contiguous(), elapsed, device=dev)
     torch.cuda.synchronize(dev)
     theta = samples.cpu().numpy()
     if not np.all(np.isfinite(theta)):
         raise SystemExit("non-finite parameters after the run")
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    variant = ens.ctx.last_variant()                      # the PF kernel the timed launches ran
+    clock_ghz, wg_cycles, _ = ens.kernel_clock()          # stamps of the last timed launch
 
     # latency of ONE chain alone on the GPU (the reference's unit: one chain, one step at a time)
     single = None
     if rank == 0 and not args.no_single_chain:
-        one = ChainEnsemble(args.model, y, p0, num_chains=1, N=N_PART, pf="poyiadjis_N", kernel=cfg["kernel"],
-                            epsilon=cfg["epsilon"], prior=prior, subsequence_length=cfg["S"],
-                            buffer_length=cfg["B"], dtype=args.dtype, seed=7, chain_offset=10 ** 6, device=dev_index)
+        one = make_ensemble(1, 7, 10 ** 6)
         one.step(2)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         one.step(5)
         torch.cuda.synchronize(dev)
         single = 5.0 / (time.perf_counter() - t1)
-    window_T = T_SERIES if cfg["S"] == -1 else (cfg["S"] + 2 * cfg["B"])
+        del one
+    n, h = STATE_STAT[model]
     wsize = 8 if args.dtype == "f64" else 4
-    bytes_per_pt = 2 * (cfg["n"] + 1 + cfg["h"]) * wsize
-    alg_bytes = float(C) * window_T * N_PART * bytes_per_pt        # per launch
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get("{0}_{1}_C{2}".format(args.model, args.dtype, C))
-            traffic = rec["bytes_per_launch"] if rec else None
-        except Exception:
-            traffic = None
-
-    # what actually bounds the LDS-resident kernel: VALU issue (4 cycles per wave64 instruction per
-    # SIMD, 1024 SIMDs at 2.4 GHz), from the committed SQ_INSTS_VALU pass of this workload
-    valu = None
-    vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
-    if os.path.exists(vpath):
-        try:
-            rec = json.load(open(vpath)).get("{0}_{1}_C{2}".format(args.model, args.dtype, C))
-            if rec:
-                insts = float(rec["SQ_INSTS_VALU_per_launch"])
-                valu = {"insts_per_launch": insts, "issue_cycles_per_inst": 4, "simds": 1024, "clock_ghz": 2.4,
-                        "issue_frac": insts * 4.0 / (1024 * 2.4e9 * kern_ms * 1e-3)}
-        except Exception:
-            valu = None
+    bytes_per_pt = 2 * (n + 1 + h) * wsize
+    alg_bytes = float(C) * w["window_T"] * w["N"] * bytes_per_pt        # per launch
+    alg_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+    key = "{0}_{1}_{2}".format(args.config, args.dtype, variant)
+    trec = (_load_json("hbm_traffic.json") or {}).get(key)
+    traffic = trec["bytes_per_launch"] * (float(C) / trec["chains"]) if trec else None
 
     if rank == 0:
         total_steps = float(C) * world * args.steps
+        streams_state = variant is not None and variant.startswith(("big", "mem"))
+        hbm_model = {"algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_gbs, "peak_GBps": HBM_PEAK_GBS,
+                     "ratio_to_peak": alg_gbs / HBM_PEAK_GBS, "binding": bool(streams_state),
+                     "note": "SURVEY 8(d) model: 2*(n+1+h)*{0} B per particle-timestep as if particle state were streamed "
+                             "through HBM every timestep".format(wsize)}
+        if streams_state:
+            roof = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel_ms": kern_ms, "in_kernel_clock_ghz": clock_ghz,
+                    "note": "large-N kernel: particle records live in a per-window HBM scratch (L2 / Infinity-Cache "
+                            "resident while it fits); the algorithmic bytes are real memory-system traffic"}
+        else:
+            vr = valu_roofline(key, C, kern_ms, clock_ghz)
+            roof = {"bound": "valu", "achieved": vr["achieved"] if vr else None, "peak": vr["peak"] if vr else None,
+                    "unit": "G VALU issue-cycles/s", "frac": vr["frac"] if vr else None, "traffic": traffic,
+                    "kernel_ms": kern_ms, "in_kernel_clock_ghz": clock_ghz, "valu": vr, "hbm_model": hbm_model,
+                    "note": "particle state is LDS-resident: HBM bounds nothing here (traffic = measured bytes per launch, "
+                            "mostly register spills); the binding resource is VALU issue.  achieved = committed per-class "
+                            "instruction counts x calibrated issue cycles per class / live kernel time; peak = 1024 SIMDs x "
+                            "live in-kernel clock"}
         line = {
-            "metric": "SGLD steps/sec (T=1000, N=1000 particles)",
+            "metric": ("SGLD steps/sec (T=1000, N=1000 particles)" if args.config == "c2"
+                       else "SGLD steps/sec ({0})".format(args.config)),
             "value": total_steps / elapsed,
             "unit": "SGLD steps/s",
-            "n_gpus": world,
+            "n_gpus": n_distinct,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -259,39 +496,32 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": w["data"],
             "config": {
-                "workload": ("SVM synthetic T=1000 N=1000, SGLD full sequence (S=-1), poyiadjis_N, prior kernel"
-                             if args.model == "svm" else
-                             "GARCH synthetic T=1000 N=1000, SGLD buffered PF S=16 B=4, poyiadjis_N, optimal kernel"),
+                "workload": w["desc"],
+                "baseline_config": args.config,
                 "chains_per_gpu": C,
                 "chains_total": C * world,
-                "rng": "device (xoshiro128++ per lane keyed by Philox4x32-10)",
-                "kernel_variant": ens.ctx.variant_name(args.model, cfg["kernel"], args.dtype, "philox", N_PART),
-                "parallelism": "independent chains, {0} GPU(s) x {1} chains, RCCL all_gather of samples".format(world, C),
+                "rng": "device",
+                "rng_precision": RNG_PRECISION,
+                "kernel_variant": variant,
+                "parallelism": "independent chains, {0} rank(s) x {1} chains, RCCL all_gather of samples".format(world, C),
             },
             "per_chain_steps_per_s": args.steps / elapsed,
             "single_chain_alone_steps_per_s": single,
-            "us_per_pf_timestep": kern_ms * 1e3 / window_T,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "state is LDS-resident by design: measured HBM traffic is far below the algorithmic bytes; "
-                        "the binding resource is VALU issue (see valu_issue)",
-                "valu_issue": valu,
-            },
+            "us_per_pf_timestep": kern_ms * 1e3 / w["window_T"],
+            "roofline": roof,
         }
-        if world == 1 and not args.no_single_chain:
+        if world != n_distinct:
+            line["rehearsal"] = "{0} ranks folded onto {1} GPU(s): NOT a multi-GPU measurement".format(world, n_distinct)
+        if world == 1 and not args.no_single_chain and args.config == "c2":
             line["parity"] = grad_error_vs_reference()
+            line["replay_arithmetic"] = replay_arithmetic_leg(w, dev_index)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.model, p0, y, prior, cfg, budget_s=args.cpu_budget)
+            line["cpu_baseline"] = cpu_baseline(w, budget_s=args.cpu_budget)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+            if single:
+                line["single_chain_speedup_vs_cpu_1core"] = single / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -73,10 +73,18 @@ __device__ __forceinline__ double wave_max(double v) {
 // 6 instructions instead of ~50 for f64).  It only has to be within a few ulp(f32) of the true
 // maximum: exp(lw - m) / sum and m + log(W/N) are invariant to it up to rounding.
 __device__ __forceinline__ float wave_max(float v) {
-#define PFG_MAX_STEP(CTRL, RM) { float o = dpp_f32<CTRL, RM>(v, v); v = o > v ? o : v; }
-    PFG_MAX_STEP(0x111, 0xf) PFG_MAX_STEP(0x112, 0xf) PFG_MAX_STEP(0x114, 0xf) PFG_MAX_STEP(0x118, 0xf)
-    PFG_MAX_STEP(0x142, 0xa) PFG_MAX_STEP(0x143, 0xc)
-#undef PFG_MAX_STEP
+    // one v_max_f32 with a DPP operand per step (the compiler lowers the builtin form to
+    // mov + mov_dpp + cmp + cndmask: 36 instructions instead of 6).  A lane whose DPP source does not
+    // exist (bound_ctrl off) or whose row is masked keeps its value; the s_nop 1 are the two wait
+    // states between a VALU write and a DPP read of the same register.
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return bcast_lane63(v);
 }
 
@@ -106,7 +114,8 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 // ------------------------------------------------------------------------------------
 struct LaneRng {
     uint32_t s0, s1, s2, s3;
-    __device__ __forceinline__ uint32_t next() {
+#ifndef PFG_RNG_JSF32
+    __device__ __forceinline__ uint32_t next() {        // xoshiro128++: 11 instructions per word
         const uint32_t sum = s0 + s3;
         const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
         const uint32_t t = s1 << 9;
@@ -115,6 +124,20 @@ struct LaneRng {
         s3 = (s3 << 11) | (s3 >> 21);
         return result;
     }
+#else
+    // -DPFG_RNG_JSF32: jsf32 (Jenkins' small fast generator, two-rotate form 27/17), 7 instructions
+    // per word against xoshiro128++'s 11.  Measured: no difference in kernel time (15.74 vs 15.78 ms
+    // per bench launch) -- the generator's integer work fills issue slots the dependency chains leave
+    // empty -- so the default stays xoshiro128++.
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t e = s0 - ((s1 << 27) | (s1 >> 5));
+        s0 = s1 ^ ((s2 << 17) | (s2 >> 15));
+        s1 = s2 + s3;
+        s2 = s3 + e;
+        s3 = e + s0;
+        return s3;
+    }
+#endif
 };
 
 __device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream, uint64_t step, uint32_t lane) {
@@ -123,7 +146,18 @@ __device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream,
                             (uint32_t)seed, (uint32_t)(seed >> 32));
     LaneRng g;
     g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w | 1u;   // never the all-zero state
+#ifdef PFG_RNG_JSF32
+#pragma unroll
+    for (int q = 0; q < 8; ++q) (void)g.next();             // jsf32: mix the key into all four words
+#endif
     return g;
+}
+
+// f64 -> u32, saturating at both ends (what v_cvt_u32_f64 does; a C cast is undefined out of range)
+__device__ __forceinline__ uint32_t cvt_u32_sat(double v) {
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // uniform in (0,1) with 32 random bits (resampling needs resolution << 1/N only)
@@ -164,9 +198,11 @@ __device__ inline void tab_fill(double *mem, bool with_rng, int tid, int nthread
     }
 }
 
-// exp(x), any x (overflow -> inf, underflow -> 0, -inf -> 0)
+// exp(x), any x (overflow -> inf, underflow -> 0, -inf -> 0).  FINITE = the caller guarantees a
+// finite argument: no clamp (a huge negative x still ends in ldexp's underflow to 0).
+template <bool FINITE = false>
 __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e2) {
-    x = fmax(x, -1000.0);
+    if (!FINITE) x = fmax(x, -1000.0);
     const double kd = rint(x * 184.6649652337873);                  // 128/ln2
     const int k = (int)kd;
 #ifdef PFG_FAST_ALGEBRA
@@ -222,6 +258,11 @@ template <typename REAL, bool TAB> struct Math;
 template <> struct Math<double, true> {
     TabF64 t;
     __device__ __forceinline__ double exp(double x) const { return exp_tab(x, t.e2); }
+#ifdef PFG_FAST_ALGEBRA
+    __device__ __forceinline__ double exp_finite(double x) const { return exp_tab<true>(x, t.e2); }
+#else
+    __device__ __forceinline__ double exp_finite(double x) const { return exp_tab(x, t.e2); }
+#endif
     __device__ __forceinline__ double log(double x) const { return log_tab(x, t.lg); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     // two independent standard normals from two words (Box-Muller, both branches).  The draws
@@ -229,17 +270,23 @@ template <> struct Math<double, true> {
     // transcendental units (v_log / v_sin / v_cos: ~12 issue slots per normal instead of ~25 for
     // a table-based fp64 evaluation) and widened; all arithmetic on the state stays fp64.
     // u1 keeps its full exponent range ((a + 0.5) 2^-32: |z| up to 6.7), the angle has 24 bits.
-    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+    __device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &z0, float &z1) const {
         const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;       // (0, 1]
         const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0,1): angle / 2pi
         const float r = sqrtf(-2.0f * __logf(u1));
-        z0 = (double)(r * __builtin_amdgcn_cosf(u2));
-        z1 = (double)(r * __builtin_amdgcn_sinf(u2));
+        z0 = r * __builtin_amdgcn_cosf(u2);
+        z1 = r * __builtin_amdgcn_sinf(u2);
+    }
+    __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
+        float f0, f1;
+        normal_pair_f32(a, b, f0, f1);
+        z0 = (double)f0; z1 = (double)f1;
     }
 };
 template <> struct Math<double, false> {
     TabF64 t;
     __device__ __forceinline__ double exp(double x) const { return ::exp(x); }
+    __device__ __forceinline__ double exp_finite(double x) const { return ::exp(x); }
     __device__ __forceinline__ double log(double x) const { return ::log(x); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
@@ -249,10 +296,16 @@ template <> struct Math<double, false> {
         sincospi((double)b * (1.0 / 2147483648.0), &sn, &cs);
         z0 = r * cs; z1 = r * sn;
     }
+    __device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &z0, float &z1) const {
+        double d0, d1;
+        normal_pair(a, b, d0, d1);
+        z0 = (float)d0; z1 = (float)d1;
+    }
 };
 template <bool TAB> struct Math<float, TAB> {
     TabF64 t;
     __device__ __forceinline__ float exp(float x) const { return __expf(x); }
+    __device__ __forceinline__ float exp_finite(float x) const { return __expf(x); }
     __device__ __forceinline__ float log(float x) const { return __logf(x); }
     __device__ __forceinline__ float sqrt(float x) const { return sqrtf(x); }
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) const {
@@ -261,6 +314,9 @@ template <bool TAB> struct Math<float, TAB> {
         const float r = sqrtf(-2.0f * __logf(u1));
         // v_sin_f32 / v_cos_f32 take their argument in revolutions
         z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
+    }
+    __device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &z0, float &z1) const {
+        normal_pair(a, b, z0, z1);
     }
 };
 

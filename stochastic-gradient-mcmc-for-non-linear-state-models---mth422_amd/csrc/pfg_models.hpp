@@ -94,7 +94,7 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
         // svm/kernels.py:34-37, :56-62; svm/helper.py:342-348
         REAL xpA = xp[0] * c.A;
         REAL x1 = c.iLQinv * z + xpA;
-        REAL e = mth.exp(-x1);
+        REAL e = mth.exp_finite(-x1);          // x1 is finite
         REAL y2 = y * y;
 #ifdef PFG_FAST_ALGEBRA
         // device-generator units (no operation-order parity to keep): the same expressions with

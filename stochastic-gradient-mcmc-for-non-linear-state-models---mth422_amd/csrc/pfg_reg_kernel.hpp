@@ -59,9 +59,11 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 //                  a division per timestep while the other waves waited at the next barrier; now wave 0
 //                  parks (W, m, w) of step t in lane t % 64 and evaluates 64 steps at once (one table log
 //                  per lane + one wave sum);
-//  PFG_OPT_RCPW    1/W by v_rcp_f64 + two Newton steps instead of the IEEE division sequence;
-//  PFG_OPT_WLMAX   every wave shifts its weights by its OWN maximum; the cross-wave maximum and the
-//                  rescaling exp(m_w - m) ride on the prefix-sum exchange: the max barrier is gone.
+//  PFG_OPT_RCPW    1/W by v_rcp_f64 + two Newton steps instead of the IEEE division sequence.
+// Measured and NOT kept (profiles/r02b_knockouts.txt): a wave-local maximum with the rescaling
+// exp(m_w - m) folded into the prefix-sum exchange (drops the max barrier, lengthens the chain behind
+// barrier 2: +4 %); the step's generator calls and Box-Muller issued between the search probes (E grows by
+// what G shrinks: +4 %); a per-workgroup start-up stagger (0 %); jsf32 instead of xoshiro128++ (0 %).
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
@@ -69,16 +71,11 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 #ifndef PFG_OPT_RCPW
 #define PFG_OPT_RCPW 1
 #endif
-#ifndef PFG_OPT_WLMAX
-#define PFG_OPT_WLMAX 0
-#endif
 #else
 #undef PFG_OPT_LAZYLL
 #undef PFG_OPT_RCPW
-#undef PFG_OPT_WLMAX
 #define PFG_OPT_LAZYLL 0
 #define PFG_OPT_RCPW 0
-#define PFG_OPT_WLMAX 0
 #endif
 // The device-generator SVM single-buffer workgroup needs 39.5 KB of LDS with the 32-bit CDF:
 // FOUR workgroups fit a CU if the kernel stays within 128 VGPRs (34 spilled registers; measured
@@ -243,7 +240,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     }
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
-    constexpr bool WLMAX = PFG_OPT_WLMAX && BLK;
     constexpr bool LAZYLL = PFG_OPT_LAZYLL && TAB && sizeof(REAL) == 8;
     double ll_W = 1.0, ll_w = 0.0;          // LAZYLL: lane t % 64 of wave 0 holds step t's (W, w, m)
     float ll_m = 0.0f;
@@ -269,18 +265,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
         for (int k = 1; k < PPT; ++k) ml = fmaxf(ml, (float)lw[k]);
         ml = wave_max(ml);
-        if (WLMAX) {
-            // wave-local shift (finite even when the wave holds no particle at all)
-            ml = fmaxf(ml, -3.0e38f);
-            m = uniform_f64((double)ml);
-            if (lane == 0) red_maxf[wave] = ml;
-            PFG_PH(0)
-            PFG_PH(1)
-        } else {
-            if (lane == 0) red_maxf[wave] = ml;
-            PFG_PH(0)
-            __syncthreads();                                                    // barrier 1
-            PFG_PH(1)
+        if (lane == 0) red_maxf[wave] = ml;
+        PFG_PH(0)
+        __syncthreads();                                                        // barrier 1
+        PFG_PH(1)
+        {
             float mm = red_maxf[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
@@ -331,35 +320,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         PFG_PH(2)
         __syncthreads();                                                        // barrier 2
         PFG_PH(3)
-        double wl_sc = 1.0;                       // WLMAX: lane w < NW holds exp(m_w - m) of wave w
-        if (WLMAX) {
-            // global maximum of the NW wave maxima (row-local DPP max over lanes 0..NW-1), every
-            // wave's rescaling factor exp(m_w - m), then the usual exclusive prefix over the RESCALED
-            // wave totals; own entries become  cs * scale_own + offset
-            const float mwl = (lane < NW) ? red_maxf[lane] : -3.0e38f;
-            float mx = mwl;
-            { float o = dpp_f32<0x111, 0xf>(mx, mx); mx = o > mx ? o : mx; }
-            if (NW > 2) { float o = dpp_f32<0x112, 0xf>(mx, mx); mx = o > mx ? o : mx; }
-            if (NW > 4) { float o = dpp_f32<0x114, 0xf>(mx, mx); mx = o > mx ? o : mx; }
-            if (NW > 8) { float o = dpp_f32<0x118, 0xf>(mx, mx); mx = o > mx ? o : mx; }
-            const float mm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), NW - 1));
-            wl_sc = (double)mth.exp((REAL)((double)mwl - (double)mm));
-            const double tot = (lane < NW) ? red_scan[lane] * wl_sc : 0.0;
-            double inc = tot;
-            if (NW > 1) inc += dpp_shr0_f64<0x111>(inc);
-            if (NW > 2) inc += dpp_shr0_f64<0x112>(inc);
-            if (NW > 4) { inc += dpp_shr0_f64<0x114>(inc); inc += dpp_shr0_f64<0x118>(inc); }
-            const double exc = inc - tot;
-            const double off = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), wave),
-                                                __builtin_amdgcn_readlane(__double2loint(exc), wave));
-            const double mysc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wl_sc), wave),
-                                                 __builtin_amdgcn_readlane(__double2loint(wl_sc), wave));
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) cs[k] = fma(cs[k], mysc, off);
-            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), NW - 1),
-                                 __builtin_amdgcn_readlane(__double2loint(inc), NW - 1));
-            m = uniform_f64((double)mm);
-        } else if (BLK) {
+        if (BLK) {
             // NW wave totals: exclusive prefix by a DPP scan over the first lanes
             const double tot = (lane < NW) ? red_scan[lane] : 0.0;
             double inc = tot;
@@ -419,10 +380,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int h = 0; h < H; ++h) {
                 double acc = 0.0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    acc += WLMAX ? red_S[h * NW + w] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wl_sc), w),
-                                                                         __builtin_amdgcn_readlane(__double2loint(wl_sc), w))
-                                 : red_S[h * NW + w];
+                for (int w = 0; w < NW; ++w) acc += red_S[h * NW + w];
                 S[h] = uniform_f64(acc * invW);
             }
         }
@@ -463,7 +421,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 const double fixs = invW * 4294967296.0;
 #pragma unroll
                 for (int k = 0; k < PPT; ++k)
-                    cdfu[cdf_phys(tid * PPT + k)] = (uint32_t)fmin(cs[k] * fixs, 4294967295.0);
+                    cdfu[cdf_phys(tid * PPT + k)] = cvt_u32_sat(cs[k] * fixs);
             }
         } else {
 #pragma unroll

@@ -74,8 +74,9 @@ class ChainEnsemble(object):
       resampling: 'multinomial' (the reference's) | 'systematic' (extension, parity-unpinned)
       sampler: 'sgld' (sample_sgld + project_parameters) | 'sghmc' (extension: momentum with
                friction `friction` in (0,1]; friction = 1 is SGLD)
-      window_sampling: 'host' (NumPy draws one window start per chain and step, descriptors are
-               re-uploaded) | 'device' (a Philox-keyed kernel rewrites the descriptors in HBM: the
+      window_sampling: 'host' (one window start per chain and step drawn on the host, keyed by
+               (seed, global chain id, step) so that a chain's windows do not depend on the rank
+               partition; descriptors are re-uploaded) | 'device' (a Philox-keyed kernel rewrites the descriptors in HBM: the
                step is three launches with no host work, and `run(..., graph_steps=K)` replays K
                steps per hipGraph launch)
     """
@@ -207,10 +208,11 @@ class ChainEnsemble(object):
         if sb > 0:       # large-N kernel: particle state lives in HBM (L2-resident), one slab per chain
             self.scratch_dev = torch.empty(self.C * sb, dtype=torch.uint8, device=dev)
             d["scratch"] = self.scratch_dev.data_ptr() + np.arange(self.C, dtype=np.uint64) * np.uint64(sb)
-        self._host_rng = np.random.RandomState((self.seed * 7919 + self.chain_offset) % (2 ** 32))
+        self.steps_done = 0
+        if (partition_style or 'uniform') == 'strict' and S > 0 and self.segments is None and self.T % S != 0:
+            raise ValueError("S {0} does not evenly divide T {1}".format(S, self.T))     # sgmcmc_sampler.py:1991-1993
         self._set_windows(first=True)
         self.desc_dev = torch.from_numpy(self._desc.view(np.uint8).reshape(self.C, -1)).to(dev)
-        self.steps_done = 0
 
     # ------------------------------------------------------------------------------------
     def _weights_for(self, start, T=None):
@@ -242,6 +244,21 @@ class ChainEnsemble(object):
                                     LRinv=np.eye(1) * th[3])
         return self._Parameters(log_mu=th[0], logit_phi=th[1], logit_lambduh=th[2], LRinv=np.eye(1) * th[3])
 
+    def _host_uniforms(self, salt):
+        """[C] uniforms in [0,1) for the step `steps_done`, one per chain, keyed by (seed, GLOBAL chain id,
+        step, salt) with a splitmix64 finaliser: a chain's window sequence does not depend on how chains
+        are partitioned over ranks (chain_offset / C), nor on what other chains do."""
+        M = np.uint64(0xFFFFFFFFFFFFFFFF)
+        with np.errstate(over="ignore"):
+            x = (np.arange(self.C, dtype=np.uint64) + np.uint64(self.chain_offset)) * np.uint64(0x9E3779B97F4A7C15)
+            x ^= np.uint64(self.seed & 0xFFFFFFFFFFFFFFFF) * np.uint64(0xD1B54A32D192ED03)
+            x ^= (np.uint64(self.steps_done) * np.uint64(0xBF58476D1CE4E5B9)) ^ (np.uint64(salt) * np.uint64(0x94D049BB133111EB))
+            for _ in range(2):
+                x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9) & M
+                x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB) & M
+                x = x ^ (x >> np.uint64(31))
+        return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
     def _set_windows(self, first=False):
         """Full sequence: static descriptors.  Buffered windows: draw one start per chain on the
         host (sgmcmc_sampler.py:259-288) and point y / weights / t1 / tL at it."""
@@ -249,15 +266,15 @@ class ChainEnsemble(object):
         if self.segments is not None:
             # one sequence per chain (np.random.choice(K, 1)), then a window inside it
             K = len(self.segments) - 1
-            seg = self._host_rng.randint(0, K, size=self.C)
+            seg = np.minimum((self._host_uniforms(1) * K).astype(np.int64), K - 1)
             base, Tk = self.segments[seg], self.segments[seg + 1] - self.segments[seg]
             S, B = self.S, self.B
             whole = Tk - S <= 0
             span = np.where(whole, 1, Tk - S + 1)
             if (self.partition_style or 'uniform') == 'strict':
-                start = np.where(whole, 0, (self._host_rng.random_sample(self.C) * np.maximum(Tk // S, 1)).astype(np.int64) * S)
+                start = np.where(whole, 0, (self._host_uniforms(2) * np.maximum(Tk // S, 1)).astype(np.int64) * S)
             else:
-                start = np.where(whole, 0, (self._host_rng.random_sample(self.C) * span).astype(np.int64))
+                start = np.where(whole, 0, (self._host_uniforms(2) * span).astype(np.int64))
             length = np.where(whole, Tk, S)
             left = np.maximum(0, start - B)
             right = np.minimum(Tk, start + length + B)
@@ -275,9 +292,9 @@ class ChainEnsemble(object):
             return False
         S, B, T = self.S, self.B, self.T
         if (self.partition_style or 'uniform') == 'strict':
-            start = self._host_rng.randint(0, T // S, size=self.C) * S
+            start = np.minimum((self._host_uniforms(2) * (T // S)).astype(np.int64), T // S - 1) * S
         else:
-            start = self._host_rng.randint(0, T - S + 1, size=self.C)
+            start = np.minimum((self._host_uniforms(2) * (T - S + 1)).astype(np.int64), T - S)
         left = np.maximum(0, start - B)
         right = np.minimum(T, start + S + B)
         d["y"] = self.y_dev.data_ptr() + left.astype(np.uint64) * 8
@@ -402,7 +419,7 @@ class ChainEnsemble(object):
         self.synchronize()
         return dict(theta=self.theta_dev.cpu().numpy(), momentum=self.momentum_dev.cpu().numpy(),
                     step_ctr=int(self.step_ctr.item()), steps_done=int(self.steps_done),
-                    host_rng=self._host_rng.get_state(), seed=self.seed, chain_offset=self.chain_offset,
+                    seed=self.seed, chain_offset=self.chain_offset,
                     model=self.model, N=self.N, C=self.C)
 
     def load_state_dict(self, state):
@@ -413,8 +430,7 @@ class ChainEnsemble(object):
         self.theta_dev.copy_(torch.from_numpy(np.ascontiguousarray(state["theta"])))
         self.momentum_dev.copy_(torch.from_numpy(np.ascontiguousarray(state["momentum"])))
         self.step_ctr.fill_(int(state["step_ctr"]))
-        self.steps_done = int(state["steps_done"])
-        self._host_rng.set_state(state["host_rng"])
+        self.steps_done = int(state["steps_done"])       # host window draws are keyed by (seed, chain, steps_done)
         self.synchronize()
 
     def synchronize(self):

@@ -96,9 +96,6 @@ def draw_replay_streams_predictive(model, N, T, t1, tL, num_steps_ahead, random_
     return z0, u, z, pred_z
 
 
-_device_rng_calls = [0]
-
-
 def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weights=None,
                  prior_mean=0.0, prior_var=1.0, stat="score", dtype="f64", rng="replay",
                  seed=None, stream=None, flags=0, random_state=None, **kwargs):
@@ -169,13 +166,14 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         q["z0"], q["u"], q["z"] = draw_replay_streams(int(N), T, random_state, buffers=bufs)
         q["_stream_bufs"] = bufs
     elif rng in ("device", "philox"):
+        # derive the device key AND stream from the host generator: (np.random state) -> (seed, stream)
+        # is a pure function, so np.random.seed() reproduces device-generator runs within and
+        # across processes
+        rs = np.random if random_state is None else random_state
         if seed is None:
-            # derive the device key from the host stream so np.random.seed() still controls runs
-            rs = np.random if random_state is None else random_state
             seed = int(rs.randint(0, 2 ** 31 - 1)) | (int(rs.randint(0, 2 ** 31 - 1)) << 31)
         if stream is None:
-            _device_rng_calls[0] += 1
-            stream = _device_rng_calls[0]
+            stream = int(rs.randint(0, 2 ** 31 - 1))
         q["seed"], q["stream"] = int(seed), int(stream)
     else:
         raise ValueError("Unrecognized rng = {0}".format(rng))

@@ -69,6 +69,41 @@ def test_chains_independent_and_reproducible():
     np.testing.assert_array_equal(a[8:], c[:8])               # global chain id, not rank, fixes a chain
 
 
+@pytest.mark.parametrize("windows", ["host", "device"])
+def test_buffered_chains_do_not_depend_on_the_rank_partition(windows):
+    """Buffered windows (S > 0): a chain's trajectory is fixed by its GLOBAL chain id -- window
+    starts included -- whether 16 chains run as one rank or as two ranks of 8 (chain_offset 0 / 8)."""
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    y = _series("svm", 120)
+    p = default_params("svm")
+
+    def run(offset, C):
+        e = ChainEnsemble("svm", y, p, num_chains=C, N=128, epsilon=0.05, seed=11, chain_offset=offset,
+                          subsequence_length=16, buffer_length=4, window_sampling=windows)
+        e.step(4)
+        e.synchronize()
+        return e.theta()
+    whole = run(0, 16)
+    np.testing.assert_array_equal(whole[:8], run(0, 8))
+    np.testing.assert_array_equal(whole[8:], run(8, 8))
+    assert len({tuple(r) for r in whole}) == 16
+
+
+def test_strict_partition_needs_divisible_length():
+    """partition_style='strict' with T % S != 0 raises as random_subsequence_and_weights does
+    (sgmcmc_sampler.py:1991-1993)."""
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    y = _series("svm", 100)
+    with pytest.raises(ValueError, match="does not evenly divide"):
+        ChainEnsemble("svm", y, default_params("svm"), num_chains=4, N=64, subsequence_length=16, buffer_length=2,
+                      partition_style="strict")
+    e = ChainEnsemble("svm", y[:96], default_params("svm"), num_chains=4, N=64, subsequence_length=16, buffer_length=2,
+                      partition_style="strict")
+    e.step(2)
+    e.synchronize()
+    assert np.all(np.isfinite(e.theta()))
+
+
 @pytest.mark.parametrize("model", ["svm", "lgssm", "garch"])
 def test_sgld_update_kernel_matches_host_formula(model):
     """theta' - theta - eps*(grad_prior + ghat)/T must be N(0, 2 eps / T) noise:

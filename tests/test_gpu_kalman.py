@@ -1,0 +1,88 @@
+"""PF score / log-likelihood against the EXACT Kalman answer (test (iii)).
+
+The only ground truth the reference has for this path: for the linear Gaussian model the gradient of
+the marginal log-likelihood is available in closed form (`LGSSMHelper.gradient_marginal_loglikelihood`,
+models/lgssm/helper.py:312-420), and the reference's own experiment compares the particle estimate with
+it (gradient_error_fig_scripts/lgssm_grad_compare.py:227-242).  `tests/golden/sampler.npz` holds the
+reference's exact gradient / log-likelihood for BASELINE config 1 (A=.9, C=1, Q=.7, R=1, T=200, data
+seed 333, prior precision of `initial_message`).  The Poyiadjis O(N) estimator is consistent with an
+O(1/N) bias, so the mean over many independent device-generator chains must approach the exact value
+like 1/N -- an analytic check of the timed device units that needs no other Monte-Carlo run.
+
+Measured (16384 chains, optimal kernel; var_dict order A, C, LQinv, LRinv):
+   N=100   bias (-0.90, 2.12, -0.46, -0.10)   SE (0.07, 0.16, 0.10, 0.10)   loglik bias -0.72
+   N=1000  bias (-0.11, 0.30, -0.09,  0.13)   SE (0.03, 0.07, 0.04, 0.05)   loglik bias -0.077
+   N=4000  bias within 2.3 SE                                                loglik bias -0.022
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENVELOPE = 400.0        # |bias| <= ENVELOPE / N + 5 SE  (observed 2.12 at N = 100, 0.30 at N = 1000)
+LL_ENVELOPE = 120.0     # |E loglik - exact| <= LL_ENVELOPE / N + 5 SE  (observed 0.72 / 0.077 / 0.022)
+
+
+def _setup(golden_sampler):
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMParameters
+    g = golden_sampler
+    y = g.get("lgssm", "y")
+    exact = g.get("lgssm", "exact_grad")                      # A, C, LQinv, LRinv
+    prec = float(g.get("lgssm", "exact_grad_prior_prec"))
+    ll = float(g.get("lgssm", "exact_loglike"))
+    p = LGSSMParameters(A=np.eye(1) * 0.9, C=np.eye(1), Q=np.eye(1) * 0.7, R=np.eye(1))
+    fm = dict(log_constant=0.0, mean_precision=np.zeros(1), precision=np.eye(1) * prec)
+    return y, p, fm, exact, ll
+
+
+def _device_mean(y, p, fm, N, C, kernel="optimal", seed=77):
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    ens = ChainEnsemble("lgssm", y, p, num_chains=C, N=N, kernel=kernel, epsilon=1e-6, seed=seed, forward_message=fm)
+    ens.launch_pf()
+    ens.synchronize()
+    s, ll = ens.last_gradient_statistics()                    # score columns [LRinv, LQinv, C, A]
+    grad = s[:, [3, 2, 1, 0]]
+    return grad.mean(0), grad.std(0) / np.sqrt(C), ll.mean(), ll.std() / np.sqrt(C), ens.ctx.last_variant()
+
+
+def test_device_units_converge_to_the_kalman_gradient(golden_sampler):
+    y, p, fm, exact, ll_exact = _setup(golden_sampler)
+    bias = {}
+    for N, C, variant in ((100, 16384, "wg64x2"), (1000, 16384, "wg256x4s"), (4000, 2048, "big4096")):
+        mean, se, ll, ll_se, v = _device_mean(y, p, fm, N, C)
+        assert v == variant
+        bias[N] = mean - exact
+        assert np.all(np.abs(bias[N]) <= ENVELOPE / N + 5 * se), (N, bias[N], se)
+        assert abs(ll - ll_exact) <= LL_ENVELOPE / N + 5 * ll_se, (N, ll, ll_exact)
+        assert ll < ll_exact + 5 * ll_se            # log of an unbiased likelihood estimate: biased DOWN (Jensen)
+    # O(1/N): ten times the particles, several times less bias
+    assert np.linalg.norm(bias[1000]) < 0.35 * np.linalg.norm(bias[100])
+    assert np.linalg.norm(bias[4000]) < np.linalg.norm(bias[1000]) + 0.3
+
+
+def test_prior_kernel_converges_too(golden_sampler):
+    """The bootstrap proposal has more variance and bias at equal N, and also vanishes like 1/N."""
+    y, p, fm, exact, _ = _setup(golden_sampler)
+    m100, se100, *_ = _device_mean(y, p, fm, 100, 16384, kernel="prior")
+    m1000, se1000, *_ = _device_mean(y, p, fm, 1000, 16384, kernel="prior")
+    assert np.all(np.abs(m1000 - exact) <= 4 * ENVELOPE / 1000 + 5 * se1000)
+    assert np.linalg.norm(m1000 - exact) < 0.5 * np.linalg.norm(m100 - exact)
+
+
+@pytest.mark.parametrize("N,runs", [(100, 512), (1000, 256)])
+def test_replay_kernel_against_the_kalman_gradient(golden_sampler, N, runs):
+    """The REPLAY instantiation (host MT19937 streams, reference operation order) on independent
+    seeds: same envelope.  One batched launch."""
+    from sgmcmc_ssm_amd import _capi
+    from sgmcmc_ssm_amd.particle_filters import make_problem
+    y, p, fm, exact, ll_exact = _setup(golden_sampler)
+    ctx = _capi.default_context(0)
+    pv = 1.0 / float(fm["precision"][0, 0])
+    probs = [make_problem("lgssm", "optimal", "poyiadjis_N", y, p.theta(), N, prior_mean=0.0, prior_var=pv,
+                          random_state=np.random.RandomState(1000 + r)) for r in range(runs)]
+    outs = ctx.run_batch(probs)
+    s = np.array([o["mean_stat"] for o in outs])[:, [3, 2, 1, 0]]
+    ll = np.array([o["loglik"] for o in outs])
+    mean, se = s.mean(0), s.std(0) / np.sqrt(runs)
+    assert np.all(np.abs(mean - exact) <= ENVELOPE / N + 5 * se), (mean - exact, se)
+    assert abs(ll.mean() - ll_exact) <= LL_ENVELOPE / N + 5 * ll.std() / np.sqrt(runs)

@@ -5,8 +5,8 @@ parallel-sum order only; the bar in BASELINE.json is gradient L2 error < 1e-4)."
 import numpy as np
 import pytest
 
-from test_host_logic import (_check_predictive, _check_sgrld, _check_sampler_case, _check_seq_and_minibatch, default_params,
-                             vec)
+from test_host_logic import (_check_eurus, _check_predictive, _check_sgrld, _check_sampler_case, _check_seq_and_minibatch,
+                             default_params, eurus_segments, vec)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-8
@@ -44,6 +44,62 @@ def test_predictive_device_rng_gpu(dtype):
     got = sampler.predictive_loglikelihood(kind="pf", num_steps_ahead=3, N=4000, rng="device", dtype=dtype)
     assert got.shape == (4,) and np.all(np.isfinite(got))
     np.testing.assert_allclose(got, ref, atol=1.5, rtol=0.02)
+
+
+def test_eurus_seq_sampler_gpu():
+    """BASELINE config 5 on its own data: SeqSVMSampler over the 49 EURUS segments, N = 10000, S = 16,
+    B = 4 (REPLAY -> large-N kernel) against the reference's gradient / SGLD / fit trajectories."""
+    _check_eurus(exact=False, rtol=RTOL)
+
+
+def test_eurus_chain_ensemble_matches_seq_sampler():
+    """The resident path of config 5: ChainEnsemble over the LIST of EURUS segments (device generator,
+    pf_big_kernel<.., 16384>) estimates the same gradient as the reference-pinned SeqSVMSampler: mean
+    over chains vs mean over replayed seeds, both at theta0, within Monte-Carlo error."""
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.models.svm import SVMParameters, SeqSVMSampler
+    g, segs = eurus_segments()
+    th = g["theta0"]
+    p = SVMParameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+    C = 2048
+    ens = ChainEnsemble("svm", segs, p, num_chains=C, N=10000, epsilon=1e-9, subsequence_length=16, buffer_length=4,
+                        seed=5)
+    ens.launch_pf()
+    ens.synchronize()
+    assert ens.ctx.last_variant() == "big16384"
+    s, _ = ens.last_gradient_statistics()               # columns [LRinv, LQinv, A], already x T_total / T_seq
+    dev_mean, dev_se = s.mean(0), s.std(0) / np.sqrt(C)
+    sampler = SeqSVMSampler(n=1, m=1, observations=segs, parameters=p)
+    runs = 96
+    ref = []
+    for r in range(runs):
+        np.random.seed(4000 + r)
+        gr = sampler.noisy_gradient(kind="pf", pf="poyiadjis_N", N=10000, subsequence_length=16, buffer_length=4,
+                                    num_sequences=1, is_scaled=False)
+        pr = sampler.prior.grad_logprior(sampler.parameters)
+        ref.append([float(np.asarray(gr[k]).reshape(-1)[0]) - float(np.asarray(pr[k]).reshape(-1)[0])
+                    for k in ("LRinv_vec", "LQinv_vec", "A")])
+    ref = np.array(ref, dtype=float).reshape(runs, 3)
+    ref_mean, ref_se = ref.mean(0), ref.std(0) / np.sqrt(runs)
+    assert np.all(np.abs(dev_mean - ref_mean) <= 5 * np.sqrt(dev_se ** 2 + ref_se ** 2)), (dev_mean, ref_mean, dev_se, ref_se)
+
+
+def test_device_generator_runs_are_a_function_of_np_random_state():
+    """rng='device' through the Sampler API: seed AND stream of the device generator come from
+    np.random, so np.random.seed(s) reproduces a run within one process (and across processes)."""
+    from sgmcmc_ssm_amd.models.svm import SVMSampler, generate_svm_data
+    np.random.seed(3)
+    p = default_params("svm")
+    y = generate_svm_data(T=100, parameters=p)["observations"]
+    sampler = SVMSampler(n=1, m=1, observations=y, parameters=p)
+    outs = []
+    for _ in range(2):
+        np.random.seed(21)
+        outs.append(vec("svm", sampler.noisy_gradient(kind="pf", N=500, rng="device", subsequence_length=-1)))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.random.seed(22)
+    other = vec("svm", sampler.noisy_gradient(kind="pf", N=500, rng="device", subsequence_length=-1))
+    assert not np.array_equal(outs[0], other)
 
 
 def test_sgrld_gpu():

@@ -213,6 +213,54 @@ def test_seq_sampler_and_minibatch_match_reference(oracle_backend, golden_sample
     _check_seq_and_minibatch(golden_sampler, model, exact=True)
 
 
+def eurus_segments():
+    """BASELINE config 5's data: the 49 gap-split EUR/USD hourly segments of the reference's demo
+    (tests/golden/eurus.npz, data arrays + reference outputs; tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eurus.npz"))
+    bounds = np.concatenate([[0], np.cumsum(g["segment_lengths"])])
+    segs = [g["segments"][bounds[k]:bounds[k + 1]].reshape(-1, 1) for k in range(len(bounds) - 1)]
+    return g, segs
+
+
+def _check_eurus(exact=True, rtol=0.0):
+    """SeqSVMSampler on the EURUS segments with the demo's settings (save_svm_params.py:60-66:
+    N = 10000, S = 16, B = 4, num_sequences = 1, epsilon = 0.001) against the reference's outputs."""
+    g, segs = eurus_segments()
+    assert len(segs) == 49 and sum(len(s) for s in segs) == 5907
+    cmp = (np.testing.assert_array_equal if exact else
+           (lambda a, b: np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol)))
+    th = g["theta0"]
+    mk = lambda t: SVMParameters(A=np.eye(1) * t[0], LQinv=np.eye(1) * t[1], LRinv=np.eye(1) * t[2])
+    pfkw = dict(kind="pf", pf="poyiadjis_N", N=10000, subsequence_length=16, buffer_length=4, num_sequences=1)
+    sampler = SeqSVMSampler(n=1, m=1, observations=segs, parameters=mk(th))
+    np.random.seed(7)
+    cmp(vec("svm", sampler.noisy_gradient(**pfkw)), g["noisy_gradient"])
+    np.random.seed(8)
+    traj = [sampler.parameters.theta()]
+    for _ in range(4):
+        sampler.sample_sgld(epsilon=0.001, **pfkw)
+        sampler.project_parameters()
+        traj.append(sampler.parameters.theta())
+    cmp(np.array(traj), g["sgld_traj"])
+    sampler = SeqSVMSampler(n=1, m=1, observations=segs, parameters=mk(th))
+    np.random.seed(9)
+    plist = sampler.fit(iter_type="SGLD", num_iters=3, output_all=True, epsilon=0.001, subsequence_length=16,
+                        num_sequences=1, buffer_length=4, kind="pf", pf_kwargs=dict(pf="poyiadjis_N", N=10000))
+    cmp(np.array([q.theta() for q in plist]), g["fit_SGLD"])
+    sampler5 = SeqSVMSampler(n=1, m=1, observations=segs[:5], parameters=mk(g["fit_SGLD"][0]))
+    np.random.seed(10)
+    cmp(vec("svm", sampler5.noisy_gradient(kind="pf", pf="poyiadjis_N", N=1000, subsequence_length=-1, buffer_length=0,
+                                           num_sequences=-1)), g["grad_all5"])
+    np.random.seed(11)
+    cmp(np.float64(sampler5.noisy_loglikelihood(kind="pf", pf="poyiadjis_N", N=1000, subsequence_length=-1,
+                                                buffer_length=0, num_sequences=-1)), g["loglike_all5"])
+
+
+def test_eurus_seq_sampler_matches_reference(oracle_backend):
+    _check_eurus(exact=True)
+
+
 def _check_predictive(model, exact=True, rtol=0.0):
     """Helper.pf_predictive_loglikelihood_estimate + Sampler/SeqSampler.predictive_loglikelihood
     (kind='pf') against the reference fixtures (tests/golden/predictive.npz)."""

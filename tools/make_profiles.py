@@ -1,0 +1,62 @@
+"""Condense the rocprofv3 passes of tools/r02_profiles.sh (gpurun_out/r02_prof/<config>/) into the
+tracked files bench.py and the judge read:
+  profiles/<tag>_<config>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+  profiles/<tag>_<config>_bench.json         the bench line of the traced run
+  profiles/valu_issue.json                   per-class VALU instruction counts per launch of the PF kernel
+  profiles/hbm_traffic.json                  FETCH_SIZE (x2: gfx950 reports half of wide reads) + WRITE_SIZE per launch
+usage: python tools/make_profiles.py <tag> [configs...]"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+cfgs = sys.argv[2:] or ["c1", "c2", "c3", "c4", "c5"]
+PROF = os.path.join(ROOT, "profiles")
+
+
+def pmc_mean(d, kernel_sub):
+    acc = collections.defaultdict(list)
+    for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if kernel_sub in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, (max(len(v) for v in acc.values()) if acc else 0)
+
+
+def load(name):
+    p = os.path.join(PROF, name)
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+valu, traffic = load("valu_issue.json"), load("hbm_traffic.json")
+valu = {k: v for k, v in valu.items() if isinstance(v, dict) and "classes" in v}        # drop round-1 records
+traffic = {k: v for k, v in traffic.items() if isinstance(v, dict) and "chains" in v}
+for c in cfgs:
+    src = os.path.join(ROOT, "gpurun_out", "r02_prof", c)
+    line = json.loads([l for l in open(os.path.join(src, "bench_trace.json")) if l.startswith("{")][-1])
+    variant, chains, dtype = line["config"]["kernel_variant"], line["config"]["chains_per_gpu"], line["dtype"]
+    ksub = "pf_big_kernel" if variant.startswith("big") else ("pf_mem_kernel" if variant.startswith("mem") else "pf_reg_kernel")
+    shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(PROF, "{0}_{1}_kernel_stats.csv".format(tag, c)))
+    json.dump(line, open(os.path.join(PROF, "{0}_{1}_bench.json".format(tag, c)), "w"), indent=1)
+    key = "{0}_{1}_{2}".format(c, dtype, variant)
+    c1, n1 = pmc_mean(os.path.join(src, "pmc_cls1"), ksub)
+    c2, n2 = pmc_mean(os.path.join(src, "pmc_cls2"), ksub)
+    if c1 and c2:
+        cls = {k.replace("SQ_INSTS_VALU_", ""): v for k, v in c1.items()}
+        cls.update({k.replace("SQ_INSTS_VALU_", ""): v for k, v in c2.items() if k.startswith("SQ_INSTS_VALU_")})
+        cls["VALU"] = c2["SQ_INSTS_VALU"]
+        valu[key] = {"chains": chains, "launches_averaged": n1, "classes": cls,
+                     "other": {k: c2[k] for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES") if k in c2},
+                     "workload": line["config"]["workload"], "source": "rocprofv3 --pmc, tools/r02_profiles.sh, " + tag}
+    f, nf = pmc_mean(os.path.join(src, "pmc_fetch"), ksub)
+    w, nw = pmc_mean(os.path.join(src, "pmc_write"), ksub)
+    if f and w:
+        # FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1 KB?  rocprofv3 documents them in KB.
+        fetch_b, write_b = f["FETCH_SIZE"] * 1024.0, w["WRITE_SIZE"] * 1024.0
+        traffic[key] = {"chains": chains, "fetch_bytes_reported": fetch_b, "fetch_bytes_corrected_x2": 2 * fetch_b,
+                        "write_bytes": write_b, "bytes_per_launch": 2 * fetch_b + write_b,
+                        "note": "separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads",
+                        "source": "tools/r02_profiles.sh, " + tag}
+    print(key, "kernel avg ns:", [r for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))) if ksub in r["Name"]][0]["AverageNs"],
+          "bench kernel_ms:", line["roofline"]["kernel_ms"], "traffic MB:", traffic.get(key, {}).get("bytes_per_launch", 0) / 1e6)
+json.dump(valu, open(os.path.join(PROF, "valu_issue.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(PROF, "hbm_traffic.json"), "w"), indent=1)
