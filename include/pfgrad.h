@@ -112,7 +112,15 @@ typedef struct pfg_problem {
     const double *paris_idx_u, *paris_acc_u, *paris_man_u;
     /* PFG_STAT_PREDICTIVE only: leads 0..num_steps_ahead; REPLAY pool of the standard normals the
      * statistic draws, pred_z [T][num_steps_ahead+1][N] (SVM, GARCH; unused for LGSSM). */
-    int32_t num_steps_ahead, reserved2;
+    int32_t num_steps_ahead;
+    /* != 0: also compute the ELEMENTWISE sufficient statistics of the window -- the reference's
+     * `elementwise_statistic=True` run (buffered_smoother.py:64-65, 201-210) behind
+     * Helper.pf_latent_var_distr (svm/helper.py:249-294): one 3-column block [x', x'^2, x x'] (GARCH:
+     * [x', x'^2, x'^4]) per window timestep, 3 (tL - t1) columns per particle, carried through the
+     * smoother's recursion.  The filter runs once (its trajectory does not depend on the statistic) and
+     * records what the recursion needs on the device; a second pass streams the [N][3 (tL-t1)]
+     * statistic matrix through HBM step by step.  NEMETH (any lambduh) and PARIS. */
+    int32_t elementwise;
     const double *pred_z;
 } pfg_problem;
 
@@ -138,6 +146,9 @@ typedef struct pfg_result {
      * rec_z [T*N]: its standard normal (as widened to f64);  rec_z0 [N]: the x0 normals. */
     uint32_t *rec_u;
     double *rec_z, *rec_z0;
+    /* pfg_problem.elementwise: ew_mean [3 (tL-t1)] = average_statistic of the elementwise run (required);
+     * ew_stats [N * 3 (tL-t1)] = its per-particle statistics, row-major (optional) */
+    double *ew_mean, *ew_stats;
 } pfg_result;
 
 /* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
@@ -170,6 +181,8 @@ typedef struct pfg_dev_problem {
     int32_t num_steps_ahead, reserved3;
     uint32_t *rec_u;         /* [T*N] or NULL: see pfg_result.rec_u (DEVICE rng, with trace_x) */
     double *rec_z, *rec_z0;  /* [T*N], [N] or NULL */
+    int32_t *trace_paris_J;  /* [T][Ntilde][N] or NULL (PARIS, with trace_x): the backward-sampled parent of
+                                every child and draw: the structure the elementwise statistics are carried through */
     uint64_t *stamps;        /* [PFG_STAMP_WORDS] or NULL (measurement): wave 0 of the workgroup writes
                                 s_memtime / s_memrealtime (100 MHz) at kernel start [0],[1] and end [2],[3]
                                 -> in-kernel shader clock = ([2]-[0]) / ([3]-[1]) * 100 MHz; [4..15]: per-phase

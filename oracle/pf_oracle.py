@@ -483,6 +483,15 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
     if save_all:
         all_x, all_lw, all_s, all_ll, all_anc = [x], [logw], [stats], [loglik], []
 
+    def widen(add, t):
+        """elementwise_statistic_wrapper (buffered_smoother.py:201-210): the h_base columns of step t
+        sit at offset (t - t1) * h_base of the wide statistic (any number of rows)."""
+        if not elementwise_statistic:
+            return add
+        wide = np.zeros((add.shape[0], h))
+        wide[:, (t - t1) * h_base:(t - t1 + 1) * h_base] = add
+        return wide
+
     for t in range(T):
         inside = (t >= t1) and (t < tL)
         weight_t = 1.0
@@ -513,9 +522,9 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             idx = np.array([ii for _ in range(N) for ii in range(N)])
             new_idx = np.array([ii for ii in range(N) for _ in range(N)])
             if inside and stat == "score":
-                add = score_statistic(model, d, x[idx], x_next[new_idx], y[t])
+                add = widen(score_statistic(model, d, x[idx], x_next[new_idx], y[t]), t)
             elif inside and stat == "suff":
-                add = sufficient_statistic(model, x[idx], x_next[new_idx])
+                add = widen(sufficient_statistic(model, x[idx], x_next[new_idx]), t)
             else:
                 add = np.zeros((N * N, h))
             add = add * weight_t
@@ -534,9 +543,9 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             rew_parents = x[flat]
             xi_next = x_next[np.array([ii for ii in range(N) for _ in range(Ntilde)])]
             if inside and stat == "score":
-                add = score_statistic(model, d, rew_parents, xi_next, y[t])
+                add = widen(score_statistic(model, d, rew_parents, xi_next, y[t]), t)
             elif inside and stat == "suff":
-                add = sufficient_statistic(model, rew_parents, xi_next)
+                add = widen(sufficient_statistic(model, rew_parents, xi_next), t)
             else:
                 add = np.zeros((N * Ntilde, h))
             add = add * weight_t
@@ -555,10 +564,8 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             add = sufficient_statistic(model, parents, x_next)
         else:
             add = np.zeros((N, h))      # zero_statistics (buffered_smoother.py:77-79)
-        if elementwise_statistic and inside and stat != "none":
-            wide = np.zeros((N, h))
-            wide[:, (t - t1) * h_base:(t - t1 + 1) * h_base] = add
-            add = wide
+        if inside and stat != "none":
+            add = widen(add, t)
         add = add * weight_t            # additive_scale
 
         if is_filter and stat == "predictive":
@@ -602,7 +609,11 @@ def latent_var_distr(model, theta, y, N, rng=np.random, **kw):
     garch/helper.py:274-318) for smoothing (lag=None): elementwise sufficient statistics,
     averaged -> (x_mean (L,1), x_cov (L,1,1))."""
     squared = kw.pop("squared", False)
-    out = pf_window_rng(model, theta, y, N, rng=rng, stat="suff", elementwise_statistic=True, **kw)
+    if kw.get("pf") == "paris":
+        kw.pop("pf")
+        out = pf_window_paris_rng(model, theta, y, N, rng=rng, stat="suff", elementwise_statistic=True, **kw)
+    else:
+        out = pf_window_rng(model, theta, y, N, rng=rng, stat="suff", elementwise_statistic=True, **kw)
     avg = np.reshape(out["mean_statistic"], (-1, 3))
     if model == "garch" and squared:
         x_mean = avg[:, 1]

@@ -39,7 +39,7 @@ struct pfg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    pfg_host::Arena in, out, desc, scratch;
+    pfg_host::Arena in, out, desc, scratch, work;      // work: device-only buffers (elementwise-statistics pass)
     std::vector<double> h_in, h_out;
     std::vector<pfg_dev_problem> h_desc;
     const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched

@@ -466,7 +466,9 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             }
             __syncthreads();
             // contribution of parent J to child ci:  stats[J] + w_t h(x_J, x_ci), added to the child's record
+            int jt_cur = 0;
             auto contribute = [&](int ci, int J) {
+                if (P.trace_x && P.trace_paris_J) P.trace_paris_J[((size_t)t * Nt + jt_cur) * N + ci] = J;
                 alignas(16) REAL rc[REC], rp[REC];
                 rec_load<REC, REAL>(rc, nxt + (size_t)ci * REC);
                 rec_load<REC, REAL>(rp, cur + (size_t)J * REC);
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             };
             const unsigned long long ltmask = (1ull << lane) - 1ull;
             for (int jt = 0; jt < Nt; ++jt) {
+                jt_cur = jt;
                 if (tid == 0) *qcount = 0;
                 __syncthreads();
                 // ---- 2. accept-reject against the filter weights, up to R rounds per child ------

@@ -791,6 +791,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const int Jk = valid[k] ? Jres[k * NT + tid] : 0;
+                    if (P.trace_x && P.trace_paris_J && valid[k])
+                        P.trace_paris_J[((size_t)t * Nt + j) * N + k * NT + tid] = Jk;
                     REAL xJ[NS], aj[H];
 #pragma unroll
                     for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + Jk];

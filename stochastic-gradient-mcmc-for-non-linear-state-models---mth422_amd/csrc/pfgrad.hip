@@ -4,6 +4,7 @@
 // small update / window / KSD kernels and the extern "C" entry points.
 #include "pfg_host.hpp"
 #include "pfg_device.hpp"
+#include "pfg_elementwise.hpp"
 
 using namespace pfg_host;
 
@@ -275,6 +276,39 @@ __global__ __launch_bounds__(256) void imq_ksd_kernel(int K, int d, const double
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- elementwise sufficient statistics: second pass over the recorded trajectory (pfg_elementwise.hpp) ----
+int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *tx, const double *tlw, const int32_t *par, int Nt,
+                     size_t Wd, double *S0, double *S1, double *Sbar, double *w, double *mean, double *stats) {
+    const int N = q.N, T = q.T, NS = state_dim(q.model);
+    const int tL = q.tL < q.T ? q.tL : q.T;
+    const double lam = q.smoother == PFG_SMOOTHER_PARIS ? 1.0 : q.lambduh;
+    hipStream_t st = ctx->stream;
+    PFG_HIP(ctx, hipMemsetAsync(S0, 0, (size_t)N * Wd * 8, st));
+    double *cur = S0, *nxt = S1;
+    const dim3 cgrid((unsigned)((Wd + 255) / 256)), sgrid((unsigned)((Wd + 255) / 256), (unsigned)N);
+    for (int t = 0; t < T; ++t) {
+        if (lam != 1.0) {
+            hipLaunchKernelGGL(pfg::ews_softmax_kernel, dim3(1), dim3(1024), 0, st, N, tlw + (size_t)t * N, w);
+            hipLaunchKernelGGL(pfg::ews_colsum_kernel, cgrid, dim3(256), 0, st, N, (int)Wd, cur, w, Sbar);
+        }
+        const bool inside = t >= q.t1 && t < tL;
+        const int col0 = inside ? 3 * (t - q.t1) : -1;
+        const double wt = (inside && q.weights) ? q.weights[t - q.t1] : 1.0;
+        const int32_t *pt = par + (size_t)t * Nt * N;
+        const double *xt = tx + (size_t)t * N * NS, *xn = tx + (size_t)(t + 1) * N * NS;
+        if (q.model == PFG_MODEL_GARCH)
+            hipLaunchKernelGGL(pfg::ews_step_kernel<PFG_MODEL_GARCH>, sgrid, dim3(256), 0, st, N, (int)Wd, Nt, lam, wt, col0, pt, xt, xn, Sbar, cur, nxt);
+        else
+            hipLaunchKernelGGL(pfg::ews_step_kernel<PFG_MODEL_SVM>, sgrid, dim3(256), 0, st, N, (int)Wd, Nt, lam, wt, col0, pt, xt, xn, Sbar, cur, nxt);
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    hipLaunchKernelGGL(pfg::ews_softmax_kernel, dim3(1), dim3(1024), 0, st, N, tlw + (size_t)T * N, w);
+    hipLaunchKernelGGL(pfg::ews_colsum_kernel, cgrid, dim3(256), 0, st, N, (int)Wd, cur, w, mean);
+    if (stats) PFG_HIP(ctx, hipMemcpyAsync(stats, cur, (size_t)N * Wd * 8, hipMemcpyDeviceToDevice, st));
+    PFG_HIP(ctx, hipGetLastError());
+    return PFG_OK;
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -321,7 +355,7 @@ void pfg_destroy(pfg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release();
+    ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release(); ctx->work.release();
     delete ctx;
 }
 
@@ -452,7 +486,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     const int NS = state_dim(model), H = stat_dim(model), P = theta_dim(model);
 
     // ---- validate + size ------------------------------------------------------------
-    size_t n_in = 0, n_out = 0;
+    size_t n_in = 0, n_out = 0, n_work = 0;
     int n_max = 0;
     for (int b = 0; b < B; ++b) {
         const pfg_problem &q = ps[b];
@@ -527,6 +561,21 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (r.trace_stats) n_out += (size_t)(q.T + 1) * q.N * H;
         if (r.trace_ll) n_out += (size_t)q.T + 1;
         if (r.trace_anc) n_out += ((size_t)q.T * q.N + 1) / 2;       /* int32 pairs in f64 slots */
+        if (q.elementwise) {
+            if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_PARIS)
+                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for pf = 'poyiadjis_N' | 'nemeth' | 'paris'");
+            if (q.stat == PFG_STAT_PREDICTIVE) return fail(ctx, PFG_ERR_INVALID, id + "elementwise statistics do not combine with the predictive statistic");
+            if (!r.ew_mean) return fail(ctx, PFG_ERR_INVALID, id + "elementwise needs ew_mean");
+            if (r.trace_x || r.trace_logw || r.trace_stats || r.trace_anc || r.rec_u || r.rec_z || r.rec_z0)
+                return fail(ctx, PFG_ERR_INVALID, id + "elementwise statistics cannot be combined with trace outputs");
+            const int tLc = q.tL < q.T ? q.tL : q.T;
+            if (tLc - q.t1 < 1) return fail(ctx, PFG_ERR_INVALID, id + "elementwise needs a non-empty window [t1, tL)");
+            const size_t Wd = 3 * (size_t)(tLc - q.t1), Nt = q.smoother == PFG_SMOOTHER_PARIS ? (size_t)q.Ntilde : 1;
+            n_out += Wd + (r.ew_stats ? (size_t)q.N * Wd : 0);
+            n_work += (size_t)(q.T + 1) * q.N * (NS + 1) + ((size_t)q.T * q.N * Nt + 1) / 2 + 2 * (size_t)q.N * Wd + Wd + q.N + 8;
+        } else if (r.ew_mean || r.ew_stats) {
+            return fail(ctx, PFG_ERR_INVALID, id + "ew_mean / ew_stats need pfg_problem.elementwise");
+        }
         if (r.rec_u || r.rec_z || r.rec_z0) {
             if (rng != PFG_RNG_DEVICE || !r.trace_x)
                 return fail(ctx, PFG_ERR_INVALID, id + "rec_u / rec_z / rec_z0 record the DEVICE generator's draws and need trace_x");
@@ -560,6 +609,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     PFG_HIP(ctx, ctx->out.ensure(n_out * 8));
     PFG_HIP(ctx, ctx->desc.ensure((size_t)B * sizeof(pfg_dev_problem)));
     if (n_scratch) PFG_HIP(ctx, ctx->scratch.ensure(n_scratch));
+    if (n_work) PFG_HIP(ctx, ctx->work.ensure(n_work * 8));
     try {
         ctx->h_in.resize(n_in);
         ctx->h_out.resize(n_out);
@@ -586,6 +636,12 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         oo += n;
         return d;
     };
+    // elementwise pass: device-only buffers (traces the filter records, the statistic matrices)
+    struct EwPlan { double *tx, *tlw, *S0, *S1, *Sbar, *w, *mean, *stats; int32_t *par; size_t Wd; int Nt; };
+    std::vector<EwPlan> ew(B, EwPlan{});
+    double *dwork = static_cast<double *>(ctx->work.ptr);
+    size_t ow = 0;
+    auto work = [&](size_t n) -> double * { double *d = dwork + ow; ow += n; return d; };
     for (int b = 0; b < B; ++b) {
         const pfg_problem &q = ps[b];
         const pfg_result &r = rs[b];
@@ -633,6 +689,20 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.trace_stats = take(r.trace_stats != nullptr, (size_t)(q.T + 1) * q.N * H);
         d.trace_ll = take(r.trace_ll != nullptr, (size_t)q.T + 1);
         d.trace_anc = reinterpret_cast<int32_t *>(take(r.trace_anc != nullptr, ((size_t)q.T * q.N + 1) / 2));
+        if (q.elementwise) {
+            EwPlan &e = ew[b];
+            e.Wd = 3 * (size_t)(tL - q.t1);
+            e.Nt = q.smoother == PFG_SMOOTHER_PARIS ? q.Ntilde : 1;
+            e.tx = work((size_t)(q.T + 1) * q.N * NS);
+            e.tlw = work((size_t)(q.T + 1) * q.N);
+            e.par = reinterpret_cast<int32_t *>(work(((size_t)q.T * q.N * e.Nt + 1) / 2));
+            e.S0 = work((size_t)q.N * e.Wd); e.S1 = work((size_t)q.N * e.Wd);
+            e.Sbar = work(e.Wd); e.w = work(q.N);
+            e.mean = take(true, e.Wd);
+            e.stats = take(r.ew_stats != nullptr, (size_t)q.N * e.Wd);
+            d.trace_x = e.tx; d.trace_logw = e.tlw;
+            if (q.smoother == PFG_SMOOTHER_PARIS) d.trace_paris_J = e.par; else d.trace_anc = e.par;
+        }
         d.rec_u = reinterpret_cast<uint32_t *>(take(r.rec_u != nullptr, ((size_t)q.T * q.N + 1) / 2));
         d.rec_z = take(r.rec_z != nullptr, (size_t)q.T * q.N);
         d.rec_z0 = take(r.rec_z0 != nullptr, q.N);
@@ -656,6 +726,12 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
                   predictive);
     if (rc) return rc;
+    for (int b = 0; b < B; ++b) {
+        if (!ps[b].elementwise) continue;
+        rc = elementwise_pass(ctx, ps[b], ew[b].tx, ew[b].tlw, ew[b].par, ew[b].Nt, ew[b].Wd, ew[b].S0, ew[b].S1,
+                              ew[b].Sbar, ew[b].w, ew[b].mean, ew[b].stats);
+        if (rc) return rc;
+    }
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, oo * 8, hipMemcpyDeviceToHost, ctx->stream));
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -688,6 +764,10 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             std::memcpy(r.rec_u, host_of(reinterpret_cast<const double *>(d.rec_u)), (size_t)q.T * q.N * 4);
         fetch(r.rec_z, d.rec_z, (size_t)q.T * q.N);
         fetch(r.rec_z0, d.rec_z0, q.N);
+        if (q.elementwise) {
+            fetch(r.ew_mean, ew[b].mean, ew[b].Wd);
+            fetch(r.ew_stats, ew[b].stats, (size_t)q.N * ew[b].Wd);
+        }
         r.status = PFG_OK;
     }
     return PFG_OK;

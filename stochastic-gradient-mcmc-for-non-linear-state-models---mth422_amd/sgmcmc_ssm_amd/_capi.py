@@ -40,7 +40,7 @@ class Problem(C.Structure):
         ("init_x", _dp), ("init_logw", _dp), ("init_stats", _dp),
         ("Ntilde", C.c_int32), ("max_accept_reject", C.c_int32),
         ("paris_idx_u", _dp), ("paris_acc_u", _dp), ("paris_man_u", _dp),
-        ("num_steps_ahead", C.c_int32), ("reserved2", C.c_int32),
+        ("num_steps_ahead", C.c_int32), ("elementwise", C.c_int32),
         ("pred_z", _dp),
     ]
 
@@ -54,6 +54,7 @@ class Result(C.Structure):
         ("trace_anc", C.POINTER(C.c_int32)),
         ("pred", C.c_double * MAX_PRED),
         ("rec_u", C.POINTER(C.c_uint32)), ("rec_z", _dp), ("rec_z0", _dp),
+        ("ew_mean", _dp), ("ew_stats", _dp),
     ]
 
 
@@ -84,6 +85,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("pred_z", "u8"), ("pred_out", "u8"), ("pred_scratch", "u8"),
     ("num_steps_ahead", "i4"), ("reserved3", "i4"),
     ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"),
+    ("trace_paris_J", "u8"),
     ("stamps", "u8"),
 ], align=True)
 
@@ -222,7 +224,7 @@ class Context:
             raise PfgError(rc, msg)
 
     # ---- host-buffer path ----------------------------------------------------------------
-    def run_batch(self, problems, want_final=False, want_trace=False, want_draws=False):
+    def run_batch(self, problems, want_final=False, want_trace=False, want_draws=False, want_elementwise=False):
         """problems: list of dicts with keys
              model, kernel, smoother, stat, dtype, rng (strings), N, T (implied by y), t1, tL,
              lambduh, prior_mean, prior_var, flags, y, weights, theta, z0,u,z | seed,stream,
@@ -292,6 +294,15 @@ class Context:
                 if not is_filter:
                     o["statistics"] = np.zeros((N, h))
                     r.stats_T = _ptr(o["statistics"])
+            if want_elementwise:
+                # elementwise sufficient statistics of the window (pf_latent_var_distr): device pass
+                L = min(p.tL, T) - p.t1
+                p.elementwise = 1
+                o["ew_mean"] = np.zeros(3 * max(L, 0))
+                r.ew_mean = _ptr(o["ew_mean"])
+                if want_final:
+                    o["ew_stats"] = np.zeros((N, 3 * max(L, 0)))
+                    r.ew_stats = _ptr(o["ew_stats"])
             if want_trace:
                 o["all_x_t"] = np.zeros((T + 1, N, ns))
                 o["all_log_weights"] = np.zeros((T + 1, N))

@@ -231,72 +231,3 @@ def average_statistic(out):
     p = np.exp(lw - np.max(lw))
     p /= np.sum(p)
     return np.sum(out["statistics"].T * p, axis=1)
-
-
-def smoothed_sufficient_statistics(model, all_x_t, all_ancestors, log_weights, t1, tL, weights=None):
-    """Per-timestep sufficient statistics along every surviving particle's lineage.
-
-    With pf='poyiadjis_N' (lambda = 1) the reference's `elementwise_statistic=True` run
-    (buffered_smoother.py:64-65, 201-210) copies the parent's whole statistic vector at every step
-    and fills in block t with h_t(x_t, x_{t+1}); the final per-particle vector is therefore just
-    h_t evaluated along that particle's ancestry.  The kernel records the genealogy
-    (`all_ancestors[t, i]` = parent of particle i at step t) and the particles; tracing it back
-    costs O(N (tL - t1)) instead of the reference's O(N (tL - t1)^2) copies.
-
-    Returns (statistics [N, 3 (tL - t1)], mean_statistic [3 (tL - t1)]) exactly as
-    out['statistics'] / average_statistic(out) of the reference."""
-    T, N = all_ancestors.shape
-    L = tL - t1
-    stats = np.zeros((N, 3 * L))
-    idx = np.arange(N)
-    for t in range(T - 1, -1, -1):
-        parents = all_ancestors[t][idx]
-        if t1 <= t < tL:
-            x_next = all_x_t[t + 1][idx]
-            x_prev = all_x_t[t][parents]
-            if model == "garch":
-                x1 = x_next[:, 0]
-                h = np.array([x1, x1 ** 2, x1 ** 4]).T
-            else:
-                h = np.hstack([x_next, x_next ** 2, x_prev * x_next])
-            w = 1.0 if weights is None else weights[t - t1]
-            stats[:, 3 * (t - t1):3 * (t - t1 + 1)] = h * w
-        idx = parents
-    p = np.exp(log_weights - np.max(log_weights))
-    p /= np.sum(p)
-    return stats, np.sum(stats.T * p, axis=1)
-
-
-def nemeth_elementwise_statistics(model, all_x_t, all_ancestors, all_log_weights, t1, tL, lambduh, weights=None):
-    """Elementwise sufficient statistics under the Nemeth smoother (lambda < 1): the recursion of
-    pf.py:138-181 with `elementwise_statistic=True` (buffered_smoother.py:201-210), replayed on
-    the host over the trajectory the device recorded (particles, genealogy, log-weights of every
-    step):   stats' = lambda stats[anc] + (1 - lambda) sum_i w_i stats_i + [block t: w_t h_t].
-    O(T N L) instead of a second device pass; an evaluation-side call (predict / smoothed marginals).
-
-    Returns (statistics [N, 3 L], mean_statistic [3 L]) as the reference's out['statistics'] /
-    average_statistic(out)."""
-    T, N = all_ancestors.shape
-    L = tL - t1
-    stats = np.zeros((N, 3 * L))
-
-    def normalize(lw):
-        p = np.exp(lw - np.max(lw))
-        p /= np.sum(p)
-        return p
-
-    for t in range(T):
-        S = np.sum(stats.T * normalize(all_log_weights[t]), axis=1)
-        anc = all_ancestors[t]
-        add = np.zeros((N, 3 * L))
-        if t1 <= t < tL:
-            x_next, x_prev = all_x_t[t + 1], all_x_t[t][anc]
-            if model == "garch":
-                x1 = x_next[:, 0]
-                h = np.array([x1, x1 ** 2, x1 ** 4]).T
-            else:
-                h = np.hstack([x_next, x_next ** 2, x_prev * x_next])
-            add[:, 3 * (t - t1):3 * (t - t1 + 1)] = h
-            add = add * (1.0 if weights is None else weights[t - t1])
-        stats = lambduh * stats[anc] + (1.0 - lambduh) * np.outer(np.ones(N), S) + add
-    return stats, np.sum(stats.T * normalize(all_log_weights[T]), axis=1)

@@ -171,37 +171,27 @@ class PFHelper(object):
                             forward_message=None, squared=False, **kwargs):
         """Smoothed marginals of the latent state on [subsequence_start, subsequence_end):
         (x_mean (L,1), x_cov (L,1,1)) -- svm/helper.py:249-294, lgssm/helper.py:1145-1198,
-        garch/helper.py:274-318.  The particle filter runs on the GPU with genealogy recording; the
-        per-timestep statistics are traced back along the lineages (particle_filters.
-        smoothed_sufficient_statistics); pf='nemeth' replays its shrinkage recursion on the host
-        over the same recorded trajectory (nemeth_elementwise_statistics).  lag=None only: the
-        reference's lag=0 / pf='filter' branch fails in average_statistic (shape mismatch); paris /
-        poyiadjis_N2 with elementwise statistics are not built."""
+        garch/helper.py:274-318: the reference's `elementwise_statistic=True` run, i.e. one block of
+        sufficient statistics per window timestep carried through the smoother's recursion.  On the GPU
+        the filter runs once (recording particles, log-weights and every child's parent(s)) and a second
+        device pass streams the [N, 3 L] statistic matrix through the recursion (pfg_problem.elementwise:
+        pf = 'poyiadjis_N' | 'nemeth' | 'paris').  lag=None only: the reference's lag=0 / pf='filter'
+        branch fails in average_statistic (shape mismatch)."""
         if lag == 0 and pf != 'filter':
             raise ValueError("pf must be filter for lag = 0")
         elif lag is None and pf == 'filter':
             raise ValueError("pf must not be filter for smoothing")
         elif lag is not None and lag != 0:
             raise NotImplementedError("lag can only be None or 0")
-        if pf not in ("poyiadjis_N", "nemeth"):
-            raise NotImplementedError("pf_latent_var_distr on the HIP backend supports pf='poyiadjis_N' | "
-                                      "'nemeth' (got '{0}')".format(pf))
+        if pf not in ("poyiadjis_N", "nemeth", "paris"):
+            raise NotImplementedError("pf_latent_var_distr on the HIP backend supports pf = 'poyiadjis_N' | "
+                                      "'nemeth' | 'paris' (got '{0}')".format(pf))
         kwargs.pop("tqdm", None)
-        lam_latent = float(kwargs.get("lambduh", 0.95)) if pf == "nemeth" else 1.0
         q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
                             pf, N, kernel, forward_message, stat="none", **kwargs)
-        o = _capi.default_context().run_batch([q], want_trace=True)[0]
+        o = _capi.default_context().run_batch([q], want_elementwise=True)[0]
         _pf._recycle_streams([q])
-        T = q["y"].shape[0]
-        tL = T if subsequence_end is None else subsequence_end
-        if pf == "nemeth":
-            _, avg = _pf.nemeth_elementwise_statistics(self.model, o["all_x_t"], o["all_ancestors"],
-                                                       o["all_log_weights"], subsequence_start, tL,
-                                                       lam_latent, weights)
-        else:
-            _, avg = _pf.smoothed_sufficient_statistics(self.model, o["all_x_t"], o["all_ancestors"],
-                                                        o["log_weights"], subsequence_start, tL, weights)
-        avg = np.reshape(avg, (-1, 3))
+        avg = np.reshape(o["ew_mean"], (-1, 3))
         if self.model == "garch" and squared:
             x_mean, x_cov = avg[:, 1], avg[:, 2] - avg[:, 1] ** 2
         else:

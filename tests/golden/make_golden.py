@@ -418,7 +418,12 @@ def make_latent_fixtures():
             ("lgssm", None, "poyiadjis_N", 150, 25, 0, None), ("lgssm", "prior", "poyiadjis_N", 100, 18, 2, 18),
             ("garch", None, "poyiadjis_N", 120, 22, 0, None), ("garch", "prior", "poyiadjis_N", 80, 16, 3, 12),
             ("svm", None, "nemeth", 150, 24, 0, None), ("lgssm", None, "nemeth", 90, 20, 3, 17),
-            ("garch", None, "nemeth", 100, 18, 2, 15)]):
+            ("garch", None, "nemeth", 100, 18, 2, 15),
+            # the smoothers the exchange-rate demos call predict(target='latent', kind='pf') with
+            ("svm", None, "paris", 120, 20, 0, None), ("svm", "prior", "paris", 80, 16, 3, 13),
+            ("lgssm", None, "paris", 100, 18, 2, 16), ("garch", None, "paris", 90, 16, 0, None),
+            ("svm", None, "poyiadjis_N2", 60, 14, 2, 12), ("lgssm", None, "poyiadjis_N2", 50, 12, 0, None),
+            ("garch", None, "poyiadjis_N2", 40, 10, 1, 9)]):
         cfg = MODEL_SETUP[model]
         p = cfg["params"]()
         np.random.seed(900 + ci)

@@ -5,7 +5,6 @@ import pytest
 from oracle import pf_oracle as po
 from conftest import Golden
 from test_host_logic import default_params, SAMPLERS, GEN
-from sgmcmc_ssm_amd import particle_filters
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +19,10 @@ def _kw(meta):
 
 
 def test_oracle_elementwise_matches_reference(golden_latent):
+    """The oracle's elementwise run reproduces the reference's pf_latent_var_distr bit for bit for every
+    smoother the reference dispatches: poyiadjis_N, nemeth, paris (np.random order) and poyiadjis_N2."""
     g = golden_latent
-    assert len(g.meta) == 9
+    assert len(g.meta) == 16 and {m["pf"] for m in g.meta} == {"poyiadjis_N", "nemeth", "paris", "poyiadjis_N2"}
     for m in g.meta:
         rng = np.random.RandomState(m["seed"])
         xm, xc = po.latent_var_distr(m["model"], g.get(m["key"], "theta"), g.get(m["key"], "y"), m["N"], rng=rng, **_kw(m))
@@ -33,50 +34,19 @@ def test_oracle_elementwise_matches_reference(golden_latent):
             assert np.array_equal(xm, g.get(m["key"], "x_mean_sq")) and np.array_equal(xc, g.get(m["key"], "x_cov_sq"))
 
 
-def test_lineage_tracing_equals_elementwise_statistics(golden_latent):
-    """Host-side genealogy tracing (product code) on the ORACLE's traces reproduces the oracle's
-    elementwise statistics bit for bit (same values, same final average)."""
-    g = golden_latent
-    for m in g.meta:
-        N = m["N"]
-        y = g.get(m["key"], "y")
-        T = y.shape[0]
-        tL = T if m["tL"] is None else m["tL"]
-        streams = po.draw_streams(np.random.RandomState(m["seed"]), N, T)
-        kw = _kw(m)
-        if m["pf"] == "nemeth":
-            # Nemeth shrinkage: the forward recursion replayed on the host over the recorded
-            # trajectory (product code) vs the oracle's elementwise run, two lambdas, +- weights
-            for lam, weights in ((None, None), (0.7, np.linspace(1.0, 2.0, tL - m["t1"]))):
-                out = po.pf_window(m["model"], g.get(m["key"], "theta"), y, N, *streams, stat="suff",
-                                   elementwise_statistic=True, save_all=True, weights=weights, lambduh=lam, **kw)
-                stats, avg = particle_filters.nemeth_elementwise_statistics(
-                    m["model"], np.array(out["all_x_t"]), np.array(out["all_ancestors"]),
-                    np.array(out["all_log_weights"]), m["t1"], tL, 0.95 if lam is None else lam, weights)
-                assert np.array_equal(stats, out["statistics"]), m
-                assert np.array_equal(avg, out["mean_statistic"]), m
-            continue
-        out = po.pf_window(m["model"], g.get(m["key"], "theta"), y, N, *streams, stat="suff",
-                           elementwise_statistic=True, save_all=True, **kw)
-        w = np.linspace(1.0, 2.0, tL - m["t1"])
-        for weights in (None, w):
-            if weights is not None:
-                out = po.pf_window(m["model"], g.get(m["key"], "theta"), y, N, *streams, stat="suff",
-                                   elementwise_statistic=True, save_all=True, weights=weights, **kw)
-            stats, avg = particle_filters.smoothed_sufficient_statistics(
-                m["model"], out["all_x_t"], out["all_ancestors"], out["log_weights"], m["t1"], tL, weights)
-            assert np.array_equal(stats, out["statistics"]), m
-            assert np.array_equal(avg, out["mean_statistic"]), m
-
-
 @pytest.mark.gpu
 def test_latent_var_distr_gpu_matches_reference(golden_latent):
+    """Helper.pf_latent_var_distr through the device elementwise pass (pfg_problem.elementwise) against
+    the reference's own outputs on identical seeds: poyiadjis_N and nemeth replay NumPy's stream."""
     from sgmcmc_ssm_amd.models.svm import SVMHelper
     from sgmcmc_ssm_amd.models.garch import GARCHHelper
     from sgmcmc_ssm_amd.models.lgssm import LGSSMHelper
     helpers = dict(svm=SVMHelper, garch=GARCHHelper, lgssm=LGSSMHelper)
     g = golden_latent
+    n = 0
     for m in g.meta:
+        if m["pf"] not in ("poyiadjis_N", "nemeth"):
+            continue
         model = m["model"]
         p = default_params(model)
         fm = None if model == "garch" else dict(log_constant=0.0, mean_precision=np.zeros(1),
@@ -94,10 +64,87 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
                                                 subsequence_start=m["t1"], subsequence_end=m["tL"], N=m["N"],
                                                 pf=m["pf"], kernel=m["kernel"], squared=True)
             np.testing.assert_allclose(xm, g.get(m["key"], "x_mean_sq"), rtol=1e-9, atol=1e-9)
+        n += 1
+    assert n == 9
     with pytest.raises(ValueError):
         helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, lag=0)
     with pytest.raises(NotImplementedError):
-        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="paris")
+        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="poyiadjis_N2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal"), ("lgssm", "prior")])
+@pytest.mark.parametrize("N,lam", [(100, 1.0), (300, 0.9), (1500, 0.95), (1500, 1.0)])
+def test_elementwise_pass_vs_oracle_nemeth(model, kernel, N, lam):
+    """The device elementwise pass (per-particle [N, 3L] statistics AND their average) against the
+    oracle's elementwise run on the same replayed streams, with importance weights, lambda < 1 and
+    N > 1024 (large-N kernel's trace)."""
+    from sgmcmc_ssm_amd import _capi
+    rs = np.random.RandomState(N)
+    T, t1, tL = 12, 2, 10
+    p = default_params(model)
+    np.random.seed(3)
+    y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
+    w = rs.uniform(1.0, 3.0, size=tL - t1)
+    z0, u, z = po.draw_streams(rs, N, T)
+    ref = po.pf_window(model, p.theta(), y, N, z0, u, z, kernel=kernel, pf="nemeth", lambduh=lam, stat="suff", t1=t1,
+                       tL=tL, weights=w, prior_mean=0.0, prior_var=1.3, elementwise_statistic=True)
+    q = dict(model=model, kernel=kernel, smoother="nemeth", stat="none", dtype="f64", rng="replay", N=N, t1=t1, tL=tL,
+             lambduh=lam, prior_mean=0.0, prior_var=1.3, y=y, weights=w, theta=p.theta(), z0=z0, u=u, z=z)
+    o = _capi.default_context(0).run_batch([q], want_final=True, want_elementwise=True)[0]
+    np.testing.assert_allclose(o["ew_stats"], ref["statistics"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(o["ew_mean"], ref["mean_statistic"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal")])
+@pytest.mark.parametrize("N,Ntilde,R", [(64, 2, 4), (300, 3, 2), (1100, 2, 3)])
+def test_elementwise_pass_vs_oracle_paris(model, kernel, N, Ntilde, R):
+    """pf='paris' (what the exchange-rate demos call predict(target='latent', kind='pf') with): chain of
+    trust as for the PaRIS gradient -- the oracle in np.random order is bit-exact vs the reference
+    (test_oracle_elementwise_matches_reference); the same oracle code on uniforms addressed by
+    (timestep, j, round, particle) is what the kernel + elementwise pass are compared with here."""
+    from sgmcmc_ssm_amd import _capi
+    rs = np.random.RandomState(N * 3 + Ntilde)
+    T, t1, tL = 8, 1, 7
+    p = default_params(model)
+    np.random.seed(4)
+    y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
+    w = rs.uniform(1.0, 3.0, size=tL - t1)
+    z0, u, z = po.draw_streams(rs, N, T)
+    idx_u = rs.random_sample((T, Ntilde, R, N))
+    acc_u = rs.random_sample((T, Ntilde, R, N))
+    man_u = rs.random_sample((T, Ntilde, N))
+    ref = po.pf_window(model, p.theta(), y, N, z0, u, z, kernel=kernel, pf="paris", stat="suff", t1=t1, tL=tL,
+                       weights=w, prior_mean=0.0, prior_var=1.3, Ntilde=Ntilde, max_accept_reject=R,
+                       manual_sample_threshold=0, paris_draws=po.PoolDraws(idx_u, acc_u, man_u),
+                       elementwise_statistic=True)
+    q = dict(model=model, kernel=kernel, smoother="paris", stat="none", dtype="f64", rng="replay", N=N, t1=t1, tL=tL,
+             prior_mean=0.0, prior_var=1.3, y=y, weights=w, theta=p.theta(), z0=z0, u=u, z=z, Ntilde=Ntilde,
+             max_accept_reject=R, paris_idx_u=idx_u, paris_acc_u=acc_u, paris_man_u=man_u)
+    o = _capi.default_context(0).run_batch([q], want_final=True, want_elementwise=True)[0]
+    np.testing.assert_allclose(o["ew_stats"], ref["statistics"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(o["ew_mean"], ref["mean_statistic"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_latent_var_distr_paris_statistics(golden_latent):
+    """Through the Helper API pf='paris' runs on the device generator: its smoothed means agree with the
+    reference's (different random numbers) within Monte-Carlo error, and with the O(N) smoother's."""
+    from sgmcmc_ssm_amd.models.svm import SVMHelper
+    g = golden_latent
+    m = [q for q in g.meta if q["pf"] == "paris" and q["model"] == "svm"][0]
+    p = default_params("svm")
+    fm = dict(log_constant=0.0, mean_precision=np.zeros(1), precision=np.eye(1) / m["prior_var"])
+    helper = SVMHelper(n=1, m=1, forward_message=fm)
+    y = g.get(m["key"], "y").reshape(-1, 1)
+    np.random.seed(1)
+    xm, xc = helper.pf_latent_var_distr(observations=y, parameters=p, pf="paris", N=4000)
+    np.random.seed(2)
+    xm2, xc2 = helper.pf_latent_var_distr(observations=y, parameters=p, pf="poyiadjis_N", N=4000)
+    assert xm.shape == (y.shape[0], 1) and np.all(xc > 0)
+    assert np.sqrt(np.mean((xm - xm2) ** 2)) < 0.15              # posterior sd ~1
+    assert np.sqrt(np.mean((xm - g.get(m["key"], "x_mean")) ** 2)) < 0.35      # reference run: N = 120 particles
 
 
 @pytest.mark.gpu
