@@ -12,7 +12,7 @@
 // Row-major [N][3L]: a child copies whole parent rows, so every access is coalesced over the column axis;
 // 16 B per matrix element per step of traffic (read parent row, write own row).  fp64 throughout.
 #pragma once
-#include "pfg_math.hpp"
+#include "pfg_models.hpp"
 
 namespace pfg {
 
@@ -91,6 +91,81 @@ __global__ __launch_bounds__(256) void ews_step_kernel(int N, int Wd, int Nt, do
         v += wt * (h * invNt);
     }
     Sn[(size_t)i * Wd + c] = v;
+}
+
+// Poyiadjis O(N^2) (pf.py:84-136) with elementwise statistics: child i averages over ALL parents with the
+// backward weights  bw_ij = softmax_j(logw_j + log q(x'_i | x_j)):
+//     S'[i][:] = sum_j bw_ij S[j][:]        block t:  += w_t sum_j bw_ij h(x_j, x'_i)
+// One workgroup per child: the N backward weights go to LDS once, then every thread owns columns and
+// walks the parents (rows of S stream through L2, coalesced over the column axis).  N <= 1024.
+template <int MODEL>
+__global__ __launch_bounds__(256) void ews_n2_step_kernel(int N, int Wd, double wt, int col0,
+                                                          const double *__restrict__ theta,
+                                                          const double *__restrict__ x_t, const double *__restrict__ logw,
+                                                          const double *__restrict__ x_next,
+                                                          const double *__restrict__ S, double *__restrict__ Sn) {
+    constexpr int NS = ModelDims<MODEL>::NS;
+    __shared__ double bw[1024];
+    __shared__ double red[4];
+    __shared__ double bx_s;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Consts<double> c = make_consts<MODEL, double>(theta);
+    const Math<double, false> mth = {};
+    double xc[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) xc[d] = x_next[(size_t)i * NS + d];
+    // log weights of the parents as seen from this child, their maximum
+    double mx = -INFINITY;
+    for (int j = tid; j < N; j += 256) {
+        double xj[NS];
+#pragma unroll
+        for (int d = 0; d < NS; ++d) xj[d] = x_t[(size_t)j * NS + d];
+        const double v = logw[j] + backward_log_ratio<MODEL, double>(c, mth, xj, xc);
+        bw[j] = v;
+        mx = fmax(mx, v);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    double sum = 0.0, sx = 0.0;
+    for (int j = tid; j < N; j += 256) {
+        const double e = exp(bw[j] - mx);
+        bw[j] = e;
+        sum += e;
+        sx = fma(e, x_t[(size_t)j * NS], sx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const double inv = 1.0 / ((red[0] + red[1]) + (red[2] + red[3]));
+    __syncthreads();
+    sx = wave_sum(sx);
+    if (lane == 0) red[wave] = sx;
+    __syncthreads();
+    if (tid == 0) bx_s = ((red[0] + red[1]) + (red[2] + red[3])) * inv;       // sum_j bw_ij x_j
+    __syncthreads();
+    const double bx = bx_s;
+    for (int col = tid; col < Wd; col += 256) {
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 1 < N; j += 2) {
+            a0 = fma(bw[j], S[(size_t)j * Wd + col], a0);
+            a1 = fma(bw[j + 1], S[(size_t)(j + 1) * Wd + col], a1);
+        }
+        if (j < N) a0 = fma(bw[j], S[(size_t)j * Wd + col], a0);
+        double v = (a0 + a1) * inv;
+        if (col0 >= 0 && col >= col0 && col < col0 + 3) {
+            const int q = col - col0;
+            const double xn = xc[0];
+            double h;
+            if (MODEL == PFG_MODEL_GARCH) h = q == 0 ? xn : (q == 1 ? xn * xn : (xn * xn) * (xn * xn));
+            else h = q == 0 ? xn : (q == 1 ? xn * xn : bx * xn);
+            v += wt * h;
+        }
+        Sn[(size_t)i * Wd + col] = v;
+    }
 }
 
 }  // namespace pfg

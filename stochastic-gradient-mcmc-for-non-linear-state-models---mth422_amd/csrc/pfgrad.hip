@@ -277,11 +277,11 @@ __global__ __launch_bounds__(256) void imq_ksd_kernel(int K, int d, const double
 }
 
 // ---- elementwise sufficient statistics: second pass over the recorded trajectory (pfg_elementwise.hpp) ----
-int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *tx, const double *tlw, const int32_t *par, int Nt,
+int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *theta_dev, const double *tx, const double *tlw, const int32_t *par, int Nt,
                      size_t Wd, double *S0, double *S1, double *Sbar, double *w, double *mean, double *stats) {
     const int N = q.N, T = q.T, NS = state_dim(q.model);
     const int tL = q.tL < q.T ? q.tL : q.T;
-    const double lam = q.smoother == PFG_SMOOTHER_PARIS ? 1.0 : q.lambduh;
+    const double lam = q.smoother == PFG_SMOOTHER_NEMETH ? q.lambduh : 1.0;
     hipStream_t st = ctx->stream;
     PFG_HIP(ctx, hipMemsetAsync(S0, 0, (size_t)N * Wd * 8, st));
     double *cur = S0, *nxt = S1;
@@ -296,7 +296,15 @@ int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *tx, const
         const double wt = (inside && q.weights) ? q.weights[t - q.t1] : 1.0;
         const int32_t *pt = par + (size_t)t * Nt * N;
         const double *xt = tx + (size_t)t * N * NS, *xn = tx + (size_t)(t + 1) * N * NS;
-        if (q.model == PFG_MODEL_GARCH)
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2) {
+            const double *lwt = tlw + (size_t)t * N;
+            if (q.model == PFG_MODEL_GARCH)
+                hipLaunchKernelGGL(pfg::ews_n2_step_kernel<PFG_MODEL_GARCH>, dim3(N), dim3(256), 0, st, N, (int)Wd, wt, col0, theta_dev, xt, lwt, xn, cur, nxt);
+            else if (q.model == PFG_MODEL_LGSSM)
+                hipLaunchKernelGGL(pfg::ews_n2_step_kernel<PFG_MODEL_LGSSM>, dim3(N), dim3(256), 0, st, N, (int)Wd, wt, col0, theta_dev, xt, lwt, xn, cur, nxt);
+            else
+                hipLaunchKernelGGL(pfg::ews_n2_step_kernel<PFG_MODEL_SVM>, dim3(N), dim3(256), 0, st, N, (int)Wd, wt, col0, theta_dev, xt, lwt, xn, cur, nxt);
+        } else if (q.model == PFG_MODEL_GARCH)
             hipLaunchKernelGGL(pfg::ews_step_kernel<PFG_MODEL_GARCH>, sgrid, dim3(256), 0, st, N, (int)Wd, Nt, lam, wt, col0, pt, xt, xn, Sbar, cur, nxt);
         else
             hipLaunchKernelGGL(pfg::ews_step_kernel<PFG_MODEL_SVM>, sgrid, dim3(256), 0, st, N, (int)Wd, Nt, lam, wt, col0, pt, xt, xn, Sbar, cur, nxt);
@@ -562,8 +570,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (r.trace_ll) n_out += (size_t)q.T + 1;
         if (r.trace_anc) n_out += ((size_t)q.T * q.N + 1) / 2;       /* int32 pairs in f64 slots */
         if (q.elementwise) {
-            if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_PARIS)
-                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for pf = 'poyiadjis_N' | 'nemeth' | 'paris'");
+            if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_PARIS && q.smoother != PFG_SMOOTHER_POYIADJIS_N2)
+                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for pf = 'poyiadjis_N' | 'nemeth' | 'paris' | 'poyiadjis_N2'");
             if (q.stat == PFG_STAT_PREDICTIVE) return fail(ctx, PFG_ERR_INVALID, id + "elementwise statistics do not combine with the predictive statistic");
             if (!r.ew_mean) return fail(ctx, PFG_ERR_INVALID, id + "elementwise needs ew_mean");
             if (r.trace_x || r.trace_logw || r.trace_stats || r.trace_anc || r.rec_u || r.rec_z || r.rec_z0)
@@ -637,7 +645,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         return d;
     };
     // elementwise pass: device-only buffers (traces the filter records, the statistic matrices)
-    struct EwPlan { double *tx, *tlw, *S0, *S1, *Sbar, *w, *mean, *stats; int32_t *par; size_t Wd; int Nt; };
+    struct EwPlan { double *tx, *tlw, *S0, *S1, *Sbar, *w, *mean, *stats; int32_t *par; size_t Wd; int Nt; const double *theta; };
     std::vector<EwPlan> ew(B, EwPlan{});
     double *dwork = static_cast<double *>(ctx->work.ptr);
     size_t ow = 0;
@@ -701,6 +709,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             e.mean = take(true, e.Wd);
             e.stats = take(r.ew_stats != nullptr, (size_t)q.N * e.Wd);
             d.trace_x = e.tx; d.trace_logw = e.tlw;
+            e.theta = d.theta;
             if (q.smoother == PFG_SMOOTHER_PARIS) d.trace_paris_J = e.par; else d.trace_anc = e.par;
         }
         d.rec_u = reinterpret_cast<uint32_t *>(take(r.rec_u != nullptr, ((size_t)q.T * q.N + 1) / 2));
@@ -728,7 +737,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     if (rc) return rc;
     for (int b = 0; b < B; ++b) {
         if (!ps[b].elementwise) continue;
-        rc = elementwise_pass(ctx, ps[b], ew[b].tx, ew[b].tlw, ew[b].par, ew[b].Nt, ew[b].Wd, ew[b].S0, ew[b].S1,
+        rc = elementwise_pass(ctx, ps[b], ew[b].theta, ew[b].tx, ew[b].tlw, ew[b].par, ew[b].Nt, ew[b].Wd, ew[b].S0, ew[b].S1,
                               ew[b].Sbar, ew[b].w, ew[b].mean, ew[b].stats);
         if (rc) return rc;
     }

@@ -175,7 +175,7 @@ class PFHelper(object):
         sufficient statistics per window timestep carried through the smoother's recursion.  On the GPU
         the filter runs once (recording particles, log-weights and every child's parent(s)) and a second
         device pass streams the [N, 3 L] statistic matrix through the recursion (pfg_problem.elementwise:
-        pf = 'poyiadjis_N' | 'nemeth' | 'paris').  lag=None only: the reference's lag=0 / pf='filter'
+        every smoother the reference dispatches: 'poyiadjis_N', 'nemeth', 'paris', 'poyiadjis_N2').  lag=None only: the reference's lag=0 / pf='filter'
         branch fails in average_statistic (shape mismatch)."""
         if lag == 0 and pf != 'filter':
             raise ValueError("pf must be filter for lag = 0")
@@ -183,9 +183,8 @@ class PFHelper(object):
             raise ValueError("pf must not be filter for smoothing")
         elif lag is not None and lag != 0:
             raise NotImplementedError("lag can only be None or 0")
-        if pf not in ("poyiadjis_N", "nemeth", "paris"):
-            raise NotImplementedError("pf_latent_var_distr on the HIP backend supports pf = 'poyiadjis_N' | "
-                                      "'nemeth' | 'paris' (got '{0}')".format(pf))
+        if pf not in ("poyiadjis_N", "nemeth", "paris", "poyiadjis_N2"):
+            raise ValueError("Unrecognized pf = {0}".format(pf))
         kwargs.pop("tqdm", None)
         q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
                             pf, N, kernel, forward_message, stat="none", **kwargs)

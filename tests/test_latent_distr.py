@@ -37,7 +37,7 @@ def test_oracle_elementwise_matches_reference(golden_latent):
 @pytest.mark.gpu
 def test_latent_var_distr_gpu_matches_reference(golden_latent):
     """Helper.pf_latent_var_distr through the device elementwise pass (pfg_problem.elementwise) against
-    the reference's own outputs on identical seeds: poyiadjis_N and nemeth replay NumPy's stream."""
+    the reference's own outputs on identical seeds: poyiadjis_N, nemeth and poyiadjis_N2 replay NumPy's stream."""
     from sgmcmc_ssm_amd.models.svm import SVMHelper
     from sgmcmc_ssm_amd.models.garch import GARCHHelper
     from sgmcmc_ssm_amd.models.lgssm import LGSSMHelper
@@ -45,7 +45,7 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
     g = golden_latent
     n = 0
     for m in g.meta:
-        if m["pf"] not in ("poyiadjis_N", "nemeth"):
+        if m["pf"] == "paris":          # data-dependent number of draws: pool parity + statistics below
             continue
         model = m["model"]
         p = default_params(model)
@@ -65,11 +65,11 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
                                                 pf=m["pf"], kernel=m["kernel"], squared=True)
             np.testing.assert_allclose(xm, g.get(m["key"], "x_mean_sq"), rtol=1e-9, atol=1e-9)
         n += 1
-    assert n == 9
+    assert n == 12
     with pytest.raises(ValueError):
         helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, lag=0)
-    with pytest.raises(NotImplementedError):
-        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="poyiadjis_N2")
+    with pytest.raises(ValueError):
+        helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, pf="filter")
 
 
 @pytest.mark.gpu
