@@ -275,6 +275,16 @@ int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, doubl
 int pfg_imq_ksd(pfg_ctx *ctx, int K, int d, const double *x, const double *g, double c, double beta,
                 double *ksd_out);
 
+/* Host helper of the REPLAY path (no GPU involved): NumPy's legacy RandomState stream of one particle-filter
+ * window, bit-identical to
+ *     z0 = rs.normal(size=N);  for t in range(T): u[t] = rs.random_sample(N); z[t] = rs.normal(size=N)
+ * -- the order in which the reference's filter consumes the global np.random state
+ * (particle_filters/pf.py:26-38, kernels.py:83-100) -- generated natively (MT19937 + polar method in one tight
+ * loop, the sqrt/log of the accepted pairs on `threads` worker threads; 0 = the default, 2).
+ * The state is RandomState.get_state()'s (key[624], pos, has_gauss, cached_gaussian), advanced in place. */
+int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, int N, int T,
+                       double *z0, double *u, double *z, int threads);
+
 #ifdef __cplusplus
 }
 #endif

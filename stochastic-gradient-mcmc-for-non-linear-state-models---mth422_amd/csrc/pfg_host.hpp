@@ -33,6 +33,24 @@ struct Arena {           // growable device buffer
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+struct HostArena {       // growable PINNED host buffer (hipHostMalloc): H2D / D2H copies from it are truly
+    double *ptr = nullptr;   // asynchronous and run at link speed; a pageable std::vector is staged by the runtime
+    size_t cap = 0;          // in doubles
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 512;
+        void *p = nullptr;
+        hipError_t e = hipHostMalloc(&p, want * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) { ptr = static_cast<double *>(p); cap = want; }
+        return e;
+    }
+    double *data() { return ptr; }
+    double &operator[](size_t i) { return ptr[i]; }
+    void release() { if (ptr) (void)hipHostFree(ptr); ptr = nullptr; cap = 0; }
+};
+
 }  // namespace pfg_host
 
 struct pfg_ctx {
@@ -40,7 +58,7 @@ struct pfg_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     pfg_host::Arena in, out, desc, scratch, work;      // work: device-only buffers (elementwise-statistics pass)
-    std::vector<double> h_in, h_out;
+    pfg_host::HostArena h_in, h_out;
     std::vector<pfg_dev_problem> h_desc;
     const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched
 };

@@ -363,7 +363,7 @@ void pfg_destroy(pfg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release(); ctx->work.release();
+    ctx->in.release(); ctx->out.release(); ctx->desc.release(); ctx->scratch.release(); ctx->work.release(); ctx->h_in.release(); ctx->h_out.release();
     delete ctx;
 }
 
@@ -473,7 +473,7 @@ int pfg_imq_ksd(pfg_ctx *ctx, int K, int d, const double *x, const double *g, do
     hipLaunchKernelGGL(imq_ksd_kernel, dim3(nblk), dim3(256), 0, ctx->stream, K, d, dx, dg, c * c, beta,
                        static_cast<double *>(ctx->out.ptr));
     PFG_HIP(ctx, hipGetLastError());
-    try { ctx->h_out.resize(nblk); } catch (const std::bad_alloc &) { return fail(ctx, PFG_ERR_NOMEM, "out of host memory"); }
+    PFG_HIP(ctx, ctx->h_out.ensure((size_t)nblk));
     PFG_HIP(ctx, hipMemcpyAsync(ctx->h_out.data(), ctx->out.ptr, (size_t)nblk * 8, hipMemcpyDeviceToHost, ctx->stream));
     PFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
@@ -619,8 +619,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     if (n_scratch) PFG_HIP(ctx, ctx->scratch.ensure(n_scratch));
     if (n_work) PFG_HIP(ctx, ctx->work.ensure(n_work * 8));
     try {
-        ctx->h_in.resize(n_in);
-        ctx->h_out.resize(n_out);
+        if (ctx->h_in.ensure(n_in) != hipSuccess || ctx->h_out.ensure(n_out) != hipSuccess) throw std::bad_alloc();
         ctx->h_desc.assign(B, pfg_dev_problem{});
     } catch (const std::bad_alloc &) {
         return fail(ctx, PFG_ERR_NOMEM, "pfg_run_batch: out of host memory");

@@ -92,7 +92,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
-           "pfg_last_variant")
+           "pfg_last_variant", "pfg_legacy_streams")
 
 _lib = None
 
@@ -158,6 +158,9 @@ def load_library():
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
     lib.pfg_variant_name.restype = C.c_char_p
+    lib.pfg_legacy_streams.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.pfg_legacy_streams.restype = C.c_int
     lib.pfg_last_variant.argtypes = [C.c_void_p]
     lib.pfg_last_variant.restype = C.c_char_p
     lib.pfg_synchronize.argtypes = [C.c_void_p]
@@ -178,6 +181,28 @@ def load_library():
     lib.pfg_sample_windows_device.restype = C.c_int
     _lib = lib
     return lib
+
+
+def legacy_streams(random_state, N, T, z0, u, z, threads=0):
+    """Fill z0 (N,), u (T,N), z (T,N) with what `random_state` (np.random or a RandomState) would return
+    for  z0 = normal(size=N); for t: u[t] = random_sample(N); z[t] = normal(size=N)  -- natively, bit for
+    bit -- and advance its state accordingly."""
+    lib = load_library()
+    rs = np.random.mtrand._rand if random_state is np.random else random_state
+    name, key, pos, has_gauss, gauss = rs.get_state()
+    if name != "MT19937":
+        raise ValueError("legacy streams need an MT19937 RandomState")
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    pos_c, hg_c, g_c = C.c_int32(int(pos)), C.c_int32(int(has_gauss)), C.c_double(float(gauss))
+    for a in (z0, u, z):
+        if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("stream buffers must be C-contiguous float64")
+    rc = lib.pfg_legacy_streams(key.ctypes.data_as(C.c_void_p), C.byref(pos_c), C.byref(hg_c), C.byref(g_c), int(N), int(T),
+                                z0.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                                int(threads))
+    if rc != 0:
+        raise PfgError(rc, "pfg_legacy_streams failed")
+    rs.set_state((name, key, pos_c.value, hg_c.value, g_c.value))
 
 
 def _as_f64(a):

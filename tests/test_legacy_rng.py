@@ -1,0 +1,48 @@
+"""libpfgrad's native generator of NumPy's legacy RandomState streams (pfg_legacy_streams) is
+bit-identical to NumPy: values, final state (key, pos, cached Gaussian), global np.random included.
+The REPLAY path's seed compatibility with the reference rests on this (host-only: no GPU needed)."""
+import numpy as np
+import pytest
+
+from sgmcmc_ssm_amd import _capi, particle_filters
+
+
+def numpy_streams(rs, N, T):
+    z0 = rs.normal(size=N)
+    u, z = np.empty((T, N)), np.empty((T, N))
+    for t in range(T):
+        u[t] = rs.random_sample(N)
+        z[t] = rs.normal(size=N)
+    return z0, u, z
+
+
+@pytest.mark.parametrize("N,T,seed,pre", [
+    (1000, 120, 1, 0), (1000, 60, 2, 1), (999, 37, 3, 0), (7, 5, 4, 1), (1, 1, 5, 0), (1001, 24, 6, 3),
+    (333, 0, 8, 1), (4000, 12, 9, 2), (10000, 6, 10, 0), (2, 500, 11, 1), (313, 77, 12, 5), (156, 311, 13, 0)])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_native_streams_bit_identical(N, T, seed, pre, threads):
+    a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+    for _ in range(pre):                 # odd numbers of earlier normals leave a cached Gaussian behind
+        a.normal(); b.normal(); a.random_sample(5); b.random_sample(5)
+    ref = numpy_streams(a, N, T)
+    z0, u, z = np.empty(N), np.empty((T, N)), np.empty((T, N))
+    _capi.legacy_streams(b, N, T, z0, u, z, threads=threads)
+    assert np.array_equal(ref[0], z0) and np.array_equal(ref[1], u) and np.array_equal(ref[2], z)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    assert a.normal() == b.normal() and np.array_equal(a.random_sample(4), b.random_sample(4))
+    assert a.randint(0, 1000) == b.randint(0, 1000)
+
+
+def test_global_np_random_and_draw_replay_streams():
+    N, T = 80, 100                        # N * T above the native threshold
+    np.random.seed(5)
+    ref = numpy_streams(np.random, N, T)
+    after = np.random.normal(size=3)
+    np.random.seed(5)
+    z0, u, z = particle_filters.draw_replay_streams(N, T)
+    assert np.array_equal(ref[0], z0) and np.array_equal(ref[1], u) and np.array_equal(ref[2], z)
+    assert np.array_equal(after, np.random.normal(size=3))
+    rs = np.random.RandomState(6)          # small windows still go through NumPy: same numbers either way
+    small = particle_filters.draw_replay_streams(10, 3, rs)
+    assert np.array_equal(small[1], numpy_streams(np.random.RandomState(6), 10, 3)[1])
