@@ -6,14 +6,23 @@
 
 namespace pfg_host {
 
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize; set it once per kernel and
+// process (again only if a larger size is asked for), not on every launch.  One process drives one GPU.
+#define PFG_ENSURE_LDS(ctx, kern, lds)                                                                    \
+    do {                                                                                                  \
+        static size_t pfg_lds_set_ = 0;                                                                   \
+        if ((lds) > 64 * 1024 && (lds) > pfg_lds_set_) {                                                  \
+            PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)));   \
+            pfg_lds_set_ = (lds);                                                                         \
+        }                                                                                                 \
+    } while (0)
+
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -40,10 +49,7 @@ int launch_paris_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, 
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_PARIS>(n_max);
     if (lds > kLdsLimit)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'paris': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -58,10 +64,7 @@ int launch_paris(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
     // large-N kernel, PaRIS instantiation (state in the HBM scratch; descriptors must carry one)
     auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, true>;
     size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -73,10 +76,7 @@ template <int MODEL, int KERNEL, typename REAL, int NP2>
 int launch_big_one(pfg_ctx *ctx, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_big_kernel<MODEL, KERNEL, REAL, NP2>;
     size_t lds = pfg::big_kernel_lds_bytes<REAL>(NP2);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -95,10 +95,7 @@ int launch_n2_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hip
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, true, pfg::MODE_N2>(n_max);
     if (lds > kLdsLimit)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2': N = " + std::to_string(n_max) + " does not fit the LDS-resident variant");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -118,10 +115,7 @@ int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp,
     auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>;
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, 256, 4, PFG_RNG_DEVICE, PP, pfg::MODE_SYSTEMATIC>(n_max);
     if (lds > kLdsLimit) return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling: state does not fit LDS");
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
@@ -131,10 +125,7 @@ template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
     size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    if (lds > 64 * 1024) {
-        PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;

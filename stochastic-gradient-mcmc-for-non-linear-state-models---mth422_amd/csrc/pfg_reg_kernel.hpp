@@ -63,7 +63,9 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // Measured and NOT kept (profiles/r02b_knockouts.txt): a wave-local maximum with the rescaling
 // exp(m_w - m) folded into the prefix-sum exchange (drops the max barrier, lengthens the chain behind
 // barrier 2: +4 %); the step's generator calls and Box-Muller issued between the search probes (E grows by
-// what G shrinks: +4 %); a per-workgroup start-up stagger (0 %); jsf32 instead of xoshiro128++ (0 %).
+// what G shrinks: +4 %); a per-workgroup start-up stagger (0 %); jsf32 instead of xoshiro128++ (0 %); the
+// model's closed-form upper bound of the log-weights as the shift (no max reduction, no max barrier, exact
+// maximum only on underflow: SVM +10 %, GARCH 0 % -- the retry path costs 9 more spilled registers).
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1

@@ -133,6 +133,42 @@ def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
     np.testing.assert_allclose(o["loglik"], ref["loglikelihood_estimate"], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("model,kernel,variant,N", [("svm", "prior", "wg256x4s", 1000), ("garch", "optimal", "wg256x4s", 600),
+                                                  ("lgssm", "optimal", "wg64x2", 100), ("svm", "prior", "wg1024x1", 1000)])
+def test_outlier_observations_on_the_device_units(ctx, monkeypatch, model, kernel, variant, N):
+    """Observations no particle explains (tens to hundreds of sigma out): log-weights of -1e2 .. -1e5.  The
+    device units must give the same trajectory as the oracle (exact-max log_normalize, pf.py:374-377).
+    Where the reference's own log-likelihood would be -inf (it is not max-stabilised,
+    buffered_smoother.py:124-126) the kernel's stays finite (DESIGN deviation (i))."""
+    T = 40
+    y = _series(model, T, seed=77)
+    y[11] = 400.0 if model != "svm" else 60.0
+    y[25] = -300.0 if model != "svm" else -45.0
+    theta = THETA[model]
+    if model == "garch":
+        pm, pv = po.garch_prior_x(theta)
+        pv = float(np.asarray(pv).reshape(-1)[0])
+    else:
+        pm, pv = 0.0, 10.0
+    NT, PPT = {"wg256x4s": (256, 4), "wg64x2": (64, 2), "wg1024x1": (1024, 1)}[variant]
+    q = dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f64", rng="device", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=pm, prior_var=pv, y=y, theta=theta, seed=31337, stream=N)
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+    assert ctx.last_variant() == variant
+    words = o["rec_u"]
+    with np.errstate(divide="ignore"):
+        ref = po.pf_window(model, theta, y, N, o["rec_z0"], None, o["rec_z"], kernel=kernel, pf="poyiadjis_N", stat="score",
+                           prior_mean=pm, prior_var=pv, save_all=True,
+                           resampler=lambda t, logw: po.device_ancestors(logw, words[t], NT, PPT, "fixed32"))
+    assert int(np.sum(o["all_ancestors"] != ref["all_ancestors"])) == 0
+    np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["all_log_weights"], ref["all_log_weights"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-7)
+    assert np.isfinite(o["loglik"]) and np.all(np.isfinite(o["mean_stat"]))
+    assert np.max(o["all_log_weights"][12]) < -100.0           # the outlier step really is one
+
+
 def test_recording_does_not_change_the_launch(ctx, monkeypatch):
     """The recorded launch is the timed launch: with and without the record / trace buffers the
     same (seed, stream) gives bitwise the same gradient (the log-likelihood sum is flushed every step
