@@ -146,6 +146,9 @@ typedef struct pfg_result {
      * rec_z [T*N]: its standard normal (as widened to f64);  rec_z0 [N]: the x0 normals. */
     uint32_t *rec_u;
     double *rec_z, *rec_z0;
+    double *rec_ud;     /* [T*N]: large-N device kernel (pf_big_kernel), whose resampling uniforms are not raw
+                           generator words but SORTED uniforms built from exponential spacings: the uniform in
+                           (0,1) child i searched the CDF with at step t (rec_u stays 0 there) */
     /* pfg_problem.elementwise: ew_mean [3 (tL-t1)] = average_statistic of the elementwise run (required);
      * ew_stats [N * 3 (tL-t1)] = its per-particle statistics, row-major (optional) */
     double *ew_mean, *ew_stats;
@@ -181,6 +184,7 @@ typedef struct pfg_dev_problem {
     int32_t num_steps_ahead, reserved3;
     uint32_t *rec_u;         /* [T*N] or NULL: see pfg_result.rec_u (DEVICE rng, with trace_x) */
     double *rec_z, *rec_z0;  /* [T*N], [N] or NULL */
+    double *rec_ud;          /* [T*N] or NULL: see pfg_result.rec_ud */
     int32_t *trace_paris_J;  /* [T][Ntilde][N] or NULL (PARIS, with trace_x): the backward-sampled parent of
                                 every child and draw: the structure the elementwise statistics are carried through */
     uint64_t *stamps;        /* [PFG_STAMP_WORDS] or NULL (measurement): wave 0 of the workgroup writes

@@ -112,7 +112,8 @@ def device_ancestors(logw, words, NT, PPT, cdf="fixed32"):
     q = tid*PPT + k holds particle k*NT + tid, slots of particles >= N weigh 0 -- and child i is
     the count of CDF entries <= its own 32-bit word `words[i]`:
       cdf='fixed32' (LDS-resident kernels): entries floor(min(cs/W * 2^32, 2^32 - 1)), integer compare;
-      cdf='f64'     (pf_big_kernel):        entries cs/W in f64 against (word + 0.5) / 2^32."""
+      cdf='f64'         entries cs/W in f64 against (word + 0.5) / 2^32;
+      cdf='f64_uniform' (pf_big_kernel): entries cs/W in f64 against the recorded uniform itself."""
     N = logw.shape[0]
     NP = NT * PPT
     q = np.arange(NP)
@@ -127,6 +128,10 @@ def device_ancestors(logw, words, NT, PPT, cdf="fixed32"):
     elif cdf == "f64":
         table = cs * (1.0 / W)
         pos = np.searchsorted(table, (words.astype(np.float64) + 0.5) * (1.0 / 4294967296.0), side="right")
+    elif cdf == "f64_uniform":
+        # pf_big_kernel: `words` are the uniforms themselves (sorted uniforms from exponential spacings)
+        table = cs * (1.0 / W)
+        pos = np.searchsorted(table, np.asarray(words, dtype=np.float64), side="right")
     else:
         raise ValueError(cdf)
     pos = np.minimum(pos, NP - 1)

@@ -5,21 +5,27 @@
 namespace pfg {
 
 // ------------------------------------------------------------------------------------
-// Large-N kernel, device-RNG fast path (N <= NP2, NP2 = 4096 | 16384): same phases and scratch
-// layout as pf_mem_kernel, restructured around what the device generator allows:
-//  * the resampling CDF is built in THREAD-major order (position tid*CH2 + j <-> particle j*1024+tid;
-//    resampling does not care how particles are labelled): one in-register running sum and ONE
-//    wave scan per thread-step instead of one scan per 1024-particle chunk;
+// Large-N kernel, device-RNG fast path (N <= NP2, NP2 = 4096 | 16384): same phases and scratch layout as
+// pf_mem_kernel, restructured around what the device generator allows:
+//  * SORTED resampling uniforms.  The N uniforms of a timestep are drawn as the order statistics of N
+//    i.i.d. uniforms -- exponential spacings e_r = -log(u_r), U_(r) = (e_1 + .. + e_r) / (e_1 + .. + e_{N+1}) --
+//    by a prefix scan that rides on the weight scan's barriers, and child r takes U_(r).  Multinomial
+//    resampling does not care which child gets which of its N uniforms; handed out in index order the
+//    children of neighbouring lanes have neighbouring (often equal) ancestors, so the parent gather -- 32-byte
+//    records out of a per-window scratch far larger than L2 -- reads runs of consecutive records instead of
+//    one random 32-byte sector per child (profiles/hbm_traffic.json: 17.0 GB of fabric traffic per launch
+//    against 9.8 GB of algorithmic bytes with independent uniforms).  CDF, ranks and storage all run in
+//    particle order; the spacings are not stored (LDS is full with the CDF) but recomputed in the sweep
+//    from a snapshot of the lane generator, their wave scan included;
 //  * the binary search is unrolled for the compile-time NP2 (probe offsets fold into the ds_read
-//    immediates) and two chunks are in flight per iteration (two independent search / gather
-//    chains per lane, and both normals of a Box-Muller pair are used);
-//  * the NW wave totals are prefix-summed redundantly by every wave with one DPP row scan,
-//    which drops a barrier.
-// REPLAY (reference index order), PaRIS and the predictive statistic stay on pf_mem_kernel.
+//    immediates, slots past N hold a sentinel) and two chunks are in flight per iteration (two independent
+//    search / gather chains per lane, and both normals of a Box-Muller pair are used).
+// REPLAY (the reference's own uniforms), PaRIS and the predictive statistic stay on pf_mem_kernel.
 // ------------------------------------------------------------------------------------
 template <typename REAL>
 __host__ __device__ inline size_t big_kernel_lds_bytes(int NP2) {
-    return ((size_t)NP2 + NP2 / 32) * 8 + (size_t)(2 * MEM_NW + PFG_MAX_STAT * MEM_NW + 8) * 8 +
+    // CDF (padded) | 4 x [chunks * waves] scan totals / offsets (weights, spacings) | wave maxima | S partials | tables
+    return ((size_t)NP2 + NP2 / 32) * 8 + (size_t)(4 * (NP2 / MEM_NT) * MEM_NW + MEM_NW + PFG_MAX_STAT * MEM_NW + 8) * 8 +
            tab_bytes<REAL, PFG_RNG_DEVICE, true>();
 }
 
@@ -30,9 +36,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NT = MEM_NT, NW = MEM_NW;
     constexpr int CH2 = NP2 / NT;                                   // CDF positions per thread (4 | 16)
-    constexpr int LOG_CH2 = CH2 == 4 ? 2 : 4;
     static_assert(CH2 == 4 || CH2 == 16, "NP2 must be 4096 or 16384");
-    static_assert(NW == 16, "the wave-total prefix is one 16-lane DPP row scan");
+    static_assert(CH2 * NW <= 4 * WAVE, "the (chunk, wave) totals are prefix-summed 4 per lane by one wave");
     constexpr int G = 2;                                            // chunks in flight
     // NP2 = 4096, f32 state: a thread's (<= 4) log-weights never leave its registers (it is the only
     // reader and writer of its particles' weights): 8 of the 40 B per particle-step stay out of
@@ -55,11 +60,15 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     const double *__restrict__ const wv = P.weights;
 
     double *cdf = reinterpret_cast<double *>(smem);                 // [NP2 + NP2/32] physical
-    double *red_scan = cdf + (NP2 + NP2 / 32);                      // [NW] wave totals
-    double *red_max = red_scan + NW;                                // [NW]
+    double *red_scan = cdf + (NP2 + NP2 / 32);                      // [CH2*NW] (chunk, wave) totals of the weights
+    double *red_scanE = red_scan + CH2 * NW;                        // [CH2*NW] ... of the exponential spacings
+    double *red_off = red_scanE + CH2 * NW;                         // [CH2*NW] exclusive offsets of red_scan
+    double *red_offE = red_off + CH2 * NW;                          // [CH2*NW] ... of red_scanE
+    double *red_max = red_offE + CH2 * NW;                          // [NW]
     float *red_maxf = reinterpret_cast<float *>(red_max);
     double *red_S = red_max + NW;                                   // [H*NW]
-    double *tabmem = red_S + PFG_MAX_STAT * NW + 8;
+    double *red_W = red_S + PFG_MAX_STAT * NW;                      // [8]: W, total of the spacings
+    double *tabmem = red_W + 8;
 
     constexpr int REC = mem_rec_len<MODEL, REAL>();
     REAL *lwg = reinterpret_cast<REAL *>(P.scratch);                // [N]
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
     mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
     tab_fill(tabmem, true, tid, NT);
+    for (int i = N + tid; i < NP2; i += NT) cdf[cdf_phys(i)] = 2.0;      // slots past N: never <= u (set once)
 
     const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
     if (P.stamps && tid == 0) { P.stamps[0] = __builtin_amdgcn_s_memtime(); P.stamps[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -153,11 +163,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
             for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
             m = uniform_f64((double)mm);
         }
-        // ---- (B,C) weights; thread-local running sums into the CDF, one wave scan ------------
+        // ---- (B,C) weights and exponential spacings: one wave scan per 1024-particle chunk each ----
         const bool needS = needS_every || (t == T);
-        double thr_exc;
+        const LaneRng rngE = rng;                 // the sweep recomputes this step's spacings from here
+        float e_extra = 0.0f;
         {
-            double part[H], run = 0.0;
+            double part[H];
 #pragma unroll
             for (int h = 0; h < H; ++h) part[h] = 0.0;
 #pragma unroll 2
@@ -173,13 +184,18 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
 #pragma unroll
                         for (int h = 0; h < H; ++h) part[h] += (double)cur[(size_t)ii * REC + NS + h] * p;
                     }
-                    run += p;
+                    const double inc = wave_incl_scan(p);
+                    if (v) cdf[cdf_phys(i)] = inc;                  // wave-local; globalised in (D)
+                    if (lane == WAVE - 1) red_scan[j * NW + wave] = inc;
+                    if (t < T) {
+                        // spacing of child i's sorted uniform (valid children only: N uniforms, N + 1 spacings)
+                        const float ef = spacing_f32(rng.next());
+                        const double incE = wave_incl_scan(v ? (double)ef : 0.0);
+                        if (lane == WAVE - 1) red_scanE[j * NW + wave] = incE;
+                    }
                 }
-                cdf[cdf_phys(tid * CH2 + j)] = run;               // positions past nchunk: flat
             }
-            const double inc = wave_incl_scan(run);
-            thr_exc = inc - run;
-            if (lane == WAVE - 1) red_scan[wave] = inc;
+            if (t < T) e_extra = spacing_f32(rng.next());           // spacing N + 1: part of the total only
             if (needS) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
@@ -189,22 +205,33 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
             }
         }
         __syncthreads();                                                        // barrier 2
-        double off_w;
-        {
-            // every wave: exclusive prefix of the 16 wave totals by one DPP row scan
-            const double tot = (lane < NW) ? red_scan[lane] : 0.0;
-            double inc = tot;
-            inc += dpp_shr0_f64<0x111>(inc);
-            inc += dpp_shr0_f64<0x112>(inc);
-            inc += dpp_shr0_f64<0x114>(inc);
-            inc += dpp_shr0_f64<0x118>(inc);
-            const double exc = inc - tot;
-            off_w = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(exc), wave),
-                                     __builtin_amdgcn_readlane(__double2loint(exc), wave));
-            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), NW - 1),
-                                 __builtin_amdgcn_readlane(__double2loint(inc), NW - 1));
+        if (wave < 2) {
+            // exclusive offsets of the nchunk*NW (chunk, wave) totals (<= 256): 4 per lane + one wave scan.
+            // Wave 0: weights; wave 1: spacings.
+            const double *src = wave == 0 ? red_scan : red_scanE;
+            double *dst = wave == 0 ? red_off : red_offE;
+            const int ntot = nchunk * NW;
+            double v4[4], loc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane * 4 + q;
+                v4[q] = (idx < ntot && (wave == 0 || t < T)) ? src[idx] : 0.0;
+                loc += v4[q];
+            }
+            const double inc = wave_incl_scan(loc);
+            double run = inc - loc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane * 4 + q;
+                if (idx < ntot) dst[idx] = run;
+                run += v4[q];
+            }
+            if (lane == WAVE - 1) red_W[wave] = inc + (wave == 1 ? (double)e_extra : 0.0);
         }
+        __syncthreads();                                                        // barrier 2b
+        W = uniform_f64(red_W[0]);
         const double invW = uniform_f64(1.0 / W);
+        const double invEtot = (t < T) ? uniform_f64(1.0 / red_W[1]) : 0.0;
         if (needS) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
@@ -225,12 +252,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
         if (t == T) break;
 
         // ---- (D) globalise + normalise the own CDF entries ---------------------------------
-        {
-            const double off = thr_exc + off_w;
 #pragma unroll 2
-            for (int j = 0; j < CH2; ++j) {
-                const int pi = cdf_phys(tid * CH2 + j);
-                cdf[pi] = (cdf[pi] + off) * invW;
+        for (int j = 0; j < CH2; ++j) {
+            const int i = j * NT + tid;
+            if (j < nchunk && i < N) {
+                const int pi = cdf_phys(i);
+                cdf[pi] = (cdf[pi] + red_off[j * NW + wave]) * invW;
             }
         }
         __syncthreads();                                                        // barrier 3
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
         const double wt = (inside && wv) ? wv[t - t1] : 1.0;
         const bool use_stat = inside && (stat != PFG_STAT_NONE);
         // ---- (E..H) two chunks per iteration: search, gather parent (L2), propose, publish ----
+        LaneRng rngS = rngE;                      // regenerates the words the scan above turned into spacings
         auto sweep = [&](auto stat_tag) {
             constexpr int STAT = decltype(stat_tag)::value;
             for (int j0 = 0; j0 < nchunk; j0 += G) {
@@ -251,10 +279,16 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                 for (int g = 0; g < G; ++g) {
                     i[g] = (j0 + g) * NT + tid;
                     v[g] = i[g] < N;
-                    const uint32_t word = rng.next();
-                    u[g] = u01_32(word);
                     a[g] = 0;
-                    if (P.trace_x && P.rec_u && v[g]) P.rec_u[(size_t)t * N + i[g]] = word;
+                    u[g] = 2.0;
+                    if (j0 + g < nchunk) {
+                        // child i's uniform = the sorted uniform of rank i: the same word, spacing and wave scan
+                        // as in (B,C), plus this (chunk, wave)'s offset
+                        const float ef = spacing_f32(rngS.next());
+                        const double incE = wave_incl_scan(v[g] ? (double)ef : 0.0);
+                        u[g] = (incE + red_offE[(j0 + g) * NW + wave]) * invEtot;
+                        if (P.trace_x && P.rec_ud && v[g]) P.rec_ud[(size_t)t * N + i[g]] = u[g];
+                    }
                 }
                 mth.normal_pair(rng.next(), rng.next(), z[0], z[1]);
                 if (P.trace_x && P.rec_z) {           // test instrumentation (see pfg_result.rec_z)
@@ -272,8 +306,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                 alignas(16) REAL rec[G][REC];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    a[g] -= (a[g] * 993) >> 15;                    // physical -> CDF position (exact < 32768)
-                    a[g] = (a[g] & (CH2 - 1)) * NT + (a[g] >> LOG_CH2);   // -> particle index
+                    a[g] -= (a[g] * 993) >> 15;                    // physical -> CDF position = particle index (exact < 32768)
                     a[g] = a[g] < N - 1 ? a[g] : N - 1;
                     rec_load<REC, REAL>(rec[g], cur + (size_t)a[g] * REC);
                 }

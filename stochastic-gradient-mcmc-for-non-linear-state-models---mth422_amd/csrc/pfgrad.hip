@@ -66,6 +66,8 @@ size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
 int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) {
     if (const char *force = std::getenv("PFGRAD_VARIANT")) {
         if (!std::strcmp(force, "mem1024") && n_max <= pfg::MEM_MAX_N) return kVariantMem;
+        // "big": the large-N kernels also where an LDS-resident variant would fit (A/B timing)
+        if (!std::strcmp(force, "big") && rng == PFG_RNG_DEVICE && n_max > 1024 && n_max <= pfg::MEM_MAX_N) return kVariantMem;
         for (int v = 0; v < kNumVariants; ++v)
             if (!std::strcmp(force, kVariants[v].tag) && n_max <= kVariants[v].NT * kVariants[v].PPT &&
                 lds_bytes(model, dtype, rng, kVariants[v], n_max) <= kLdsLimit)
@@ -574,7 +576,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                 return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for pf = 'poyiadjis_N' | 'nemeth' | 'paris' | 'poyiadjis_N2'");
             if (q.stat == PFG_STAT_PREDICTIVE) return fail(ctx, PFG_ERR_INVALID, id + "elementwise statistics do not combine with the predictive statistic");
             if (!r.ew_mean) return fail(ctx, PFG_ERR_INVALID, id + "elementwise needs ew_mean");
-            if (r.trace_x || r.trace_logw || r.trace_stats || r.trace_anc || r.rec_u || r.rec_z || r.rec_z0)
+            if (r.trace_x || r.trace_logw || r.trace_stats || r.trace_anc || r.rec_u || r.rec_z || r.rec_z0 || r.rec_ud)
                 return fail(ctx, PFG_ERR_INVALID, id + "elementwise statistics cannot be combined with trace outputs");
             const int tLc = q.tL < q.T ? q.tL : q.T;
             if (tLc - q.t1 < 1) return fail(ctx, PFG_ERR_INVALID, id + "elementwise needs a non-empty window [t1, tL)");
@@ -584,12 +586,13 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         } else if (r.ew_mean || r.ew_stats) {
             return fail(ctx, PFG_ERR_INVALID, id + "ew_mean / ew_stats need pfg_problem.elementwise");
         }
-        if (r.rec_u || r.rec_z || r.rec_z0) {
+        if (r.rec_u || r.rec_z || r.rec_z0 || r.rec_ud) {
             if (rng != PFG_RNG_DEVICE || !r.trace_x)
                 return fail(ctx, PFG_ERR_INVALID, id + "rec_u / rec_z / rec_z0 record the DEVICE generator's draws and need trace_x");
             if (r.rec_u) n_out += ((size_t)q.T * q.N + 1) / 2;
             if (r.rec_z) n_out += (size_t)q.T * q.N;
             if (r.rec_z0) n_out += q.N;
+            if (r.rec_ud) n_out += (size_t)q.T * q.N;
         }
         if (r.trace_anc && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_anc needs trace_x");
         if ((r.logw_T || r.stats_T) && !r.x_T) return fail(ctx, PFG_ERR_INVALID, id + "logw_T/stats_T need x_T");
@@ -714,6 +717,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.rec_u = reinterpret_cast<uint32_t *>(take(r.rec_u != nullptr, ((size_t)q.T * q.N + 1) / 2));
         d.rec_z = take(r.rec_z != nullptr, (size_t)q.T * q.N);
         d.rec_z0 = take(r.rec_z0 != nullptr, q.N);
+        d.rec_ud = take(r.rec_ud != nullptr, (size_t)q.T * q.N);
         d.step_ctr = nullptr;
         d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
                               : nullptr;
@@ -772,6 +776,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             std::memcpy(r.rec_u, host_of(reinterpret_cast<const double *>(d.rec_u)), (size_t)q.T * q.N * 4);
         fetch(r.rec_z, d.rec_z, (size_t)q.T * q.N);
         fetch(r.rec_z0, d.rec_z0, q.N);
+        fetch(r.rec_ud, d.rec_ud, (size_t)q.T * q.N);
         if (q.elementwise) {
             fetch(r.ew_mean, ew[b].mean, ew[b].Wd);
             fetch(r.ew_stats, ew[b].stats, (size_t)q.N * ew[b].Wd);

@@ -54,6 +54,7 @@ class Result(C.Structure):
         ("trace_anc", C.POINTER(C.c_int32)),
         ("pred", C.c_double * MAX_PRED),
         ("rec_u", C.POINTER(C.c_uint32)), ("rec_z", _dp), ("rec_z0", _dp),
+        ("rec_ud", _dp),
         ("ew_mean", _dp), ("ew_stats", _dp),
     ]
 
@@ -85,7 +86,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("pred_z", "u8"), ("pred_out", "u8"), ("pred_scratch", "u8"),
     ("num_steps_ahead", "i4"), ("reserved3", "i4"),
     ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"),
-    ("trace_paris_J", "u8"),
+    ("rec_ud", "u8"), ("trace_paris_J", "u8"),
     ("stamps", "u8"),
 ], align=True)
 
@@ -346,6 +347,8 @@ class Context:
                     o["rec_z0"] = np.zeros(N)
                     r.rec_u = o["rec_u"].ctypes.data_as(C.POINTER(C.c_uint32))
                     r.rec_z, r.rec_z0 = _ptr(o["rec_z"]), _ptr(o["rec_z0"])
+                    o["rec_ud"] = np.zeros((T, N))
+                    r.rec_ud = _ptr(o["rec_ud"])
             outs.append(o)
         self._check(self.lib.pfg_run_batch(self.handle, B, ps, rs))
         for b, o in enumerate(outs):

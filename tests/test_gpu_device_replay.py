@@ -3,7 +3,8 @@
 The REPLAY kernels are pinned to the reference through NumPy's legacy stream; the device-generator
 kernels live in other translation units (-ffp-contract=fast -DPFG_FAST_ALGEBRA: fused multiply-adds,
 a cubic expm1, a 32-bit fixed-point resampling CDF in thread-major order searched with the raw
-generator word, Gaussian draws from the f32 transcendental units), so REPLAY parity says nothing
+generator word -- or, in the large-N kernel, sorted uniforms built from exponential spacings --,
+Gaussian draws from the f32 transcendental units), so REPLAY parity says nothing
 about them.  Here the SAME instantiation (same template arguments, same code object) additionally
 writes out the random inputs it consumed -- per step and child the 32-bit word it searched the CDF
 with and its standard normal, plus the x0 normals (pfg_result.rec_u / rec_z / rec_z0) -- and the
@@ -78,9 +79,10 @@ CASES = [
     # config 4: SVM N=4000, LDS-resident 1024 x 4
     ("svm", "prior", "poyiadjis_N", 1.0, 4000, 250, None, "wg1024x4s", (1024, 4, "fixed32")),
     # config 5: SVM N=10000, S=16 B=4 window, large-N kernel (fp64 CDF)
-    ("svm", "prior", "poyiadjis_N", 1.0, 10000, 24, (4, 20, True), "big16384", (1024, 16, "f64")),
-    ("garch", "optimal", "poyiadjis_N", 1.0, 4000, 40, None, "big4096", (1024, 4, "f64")),
-    ("lgssm", "optimal", "nemeth", 0.95, 3000, 40, None, "big4096", (1024, 4, "f64")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 10000, 24, (4, 20, True), "big16384", (16384, 1, "f64_uniform")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 9001, 30, None, "big16384", (16384, 1, "f64_uniform")),
+    ("garch", "optimal", "poyiadjis_N", 1.0, 4000, 40, None, "big4096", (4096, 1, "f64_uniform")),
+    ("lgssm", "optimal", "nemeth", 0.95, 3000, 40, None, "big4096", (4096, 1, "f64_uniform")),
 ]
 
 
@@ -113,6 +115,15 @@ def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
     assert ctx.last_variant() == variant          # the instantiation under test really ran
 
     words, z, z0 = o["rec_u"], o["rec_z"], o["rec_z0"]
+    if cdf == "f64_uniform":
+        # large-N kernel: the recorded resampling inputs are the sorted uniforms themselves (CDF, ranks and
+        # storage all in particle order); per step they must be what they claim to be: in (0, 1) and
+        # increasing in child order
+        words = o["rec_ud"]
+        assert np.all((words > 0.0) & (words < 1.0))
+        child = np.arange(N)
+        rank = (child % NT) * PPT + child // NT
+        assert np.all(np.diff(words[:, np.argsort(rank)], axis=1) >= 0.0)
     assert np.all(np.isfinite(z)) and np.all(np.isfinite(z0)) and np.any(words != 0)
     ref = po.pf_window(model, theta, y, N, z0, None, z, kernel=kernel, pf=pf, lambduh=lam, stat="score",
                        t1=t1, tL=tL, weights=weights, prior_mean=pm, prior_var=pv, save_all=True,
