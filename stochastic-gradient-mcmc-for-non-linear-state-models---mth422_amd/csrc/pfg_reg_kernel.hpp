@@ -65,7 +65,10 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // barrier 2: +4 %); the step's generator calls and Box-Muller issued between the search probes (E grows by
 // what G shrinks: +4 %); a per-workgroup start-up stagger (0 %); jsf32 instead of xoshiro128++ (0 %); the
 // model's closed-form upper bound of the log-weights as the shift (no max reduction, no max barrier, exact
-// maximum only on underflow: SVM +10 %, GARCH 0 % -- the retry path costs 9 more spilled registers).
+// maximum only on underflow: SVM +10 %, GARCH 0 % -- the retry path costs 9 more spilled registers); the
+// step's words / normals drawn behind barrier 2, next to the serial offsets chain (+10 %: 4-8 more live
+// registers); search levels 1-3 compared in registers against 7 broadcast pivots (7 instead of 10 dependent
+// LDS round trips: 0 % -- the search is issue-bound, not LDS-latency-bound).
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
