@@ -357,6 +357,8 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="0 = the config's default")
     ap.add_argument("--model", default=None, choices=["svm", "garch"], help="(compat) svm = c2, garch = c3")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--sampler", default="sgld", choices=["sgld", "sghmc"],
+                    help="sghmc: the extension BASELINE configs[4] names (momentum update, friction 0.1); same PF launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-chain", action="store_true",
                     help="skip the one-chain-alone latency, replay-arithmetic and parity legs (profiling runs: keeps every "
@@ -404,7 +406,8 @@ def main():
     def make_ensemble(chains, seed, offset):
         return ChainEnsemble(model, w["y"], w["p0"], num_chains=chains, N=w["N"], pf="poyiadjis_N", kernel=w["kernel"],
                              epsilon=w["epsilon"], prior=w["prior"], subsequence_length=w["S"], buffer_length=w["B"],
-                             dtype=args.dtype, seed=seed, chain_offset=offset, device=dev_index)
+                             dtype=args.dtype, seed=seed, chain_offset=offset, device=dev_index,
+                             sampler=args.sampler, friction=0.1)
 
     ens = make_ensemble(C, 2024, lo)
     ens.enable_stamps()
@@ -503,6 +506,7 @@ def main():
                 "chains_per_gpu": C,
                 "chains_total": C * world,
                 "rng": "device",
+                "sampler": args.sampler + (" (extension: not in the reference, parity-unpinned)" if args.sampler == "sghmc" else ""),
                 "rng_precision": RNG_PRECISION,
                 "kernel_variant": variant,
                 "parallelism": "independent chains, {0} rank(s) x {1} chains, RCCL all_gather of samples".format(world, C),

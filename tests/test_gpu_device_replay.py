@@ -180,6 +180,40 @@ def test_outlier_observations_on_the_device_units(ctx, monkeypatch, model, kerne
     assert np.max(o["all_log_weights"][12]) < -100.0           # the outlier step really is one
 
 
+@pytest.mark.parametrize("model,kernel,N,T,variant,layout", [
+    ("svm", "prior", 1000, 24, "wg256x4", (256, 4, "fixed32")),          # f32 default: ping-pong
+    ("garch", "optimal", 1000, 24, "wg256x4", (256, 4, "fixed32")),
+    ("lgssm", "optimal", 100, 40, "wg64x2", (64, 2, "fixed32")),
+    ("svm", "prior", 4000, 16, "wg1024x4s", (1024, 4, "fixed32"))])
+def test_f32_state_device_kernels_replayed(ctx, monkeypatch, model, kernel, N, T, variant, layout):
+    """dtype='f32' (particle state and statistics in f32, weights / CDF / search in f64): the same replay on
+    short windows, at f32 tolerance.  (Over long windows an f32 weight differs from the oracle's by ~1e-7,
+    which eventually flips an ancestor and the trajectories part: SURVEY finding 2.)"""
+    NT, PPT, cdf = layout
+    theta = THETA[model]
+    y = _series(model, T, seed=3 * N + T)
+    if model == "garch":
+        pm, pv = po.garch_prior_x(theta)
+        pv = float(np.asarray(pv).reshape(-1)[0])
+    else:
+        pm, pv = 0.0, 10.0
+    q = dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f32", rng="device", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=pm, prior_var=pv, y=y, theta=theta, seed=777 + N, stream=T)
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+    assert ctx.last_variant() == variant
+    words = o["rec_u"]
+    ref = po.pf_window(model, theta, y, N, o["rec_z0"], None, o["rec_z"], kernel=kernel, pf="poyiadjis_N", stat="score",
+                       prior_mean=pm, prior_var=pv, save_all=True,
+                       resampler=lambda t, logw: po.device_ancestors(logw, words[t], NT, PPT, cdf))
+    assert int(np.sum(o["all_ancestors"] != ref["all_ancestors"])) == 0
+    np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(o["all_log_weights"], ref["all_log_weights"], rtol=2e-4, atol=2e-4)
+    scale = np.maximum(1.0, np.abs(ref["all_statistics"]).max())
+    assert np.max(np.abs(o["all_statistics"] - ref["all_statistics"])) < 2e-4 * scale
+    np.testing.assert_allclose(o["loglik"], ref["loglikelihood_estimate"], rtol=1e-5, atol=1e-3)
+
+
 def test_recording_does_not_change_the_launch(ctx, monkeypatch):
     """The recorded launch is the timed launch: with and without the record / trace buffers the
     same (seed, stream) gives bitwise the same gradient (the log-likelihood sum is flushed every step

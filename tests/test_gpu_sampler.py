@@ -84,6 +84,28 @@ def test_eurus_chain_ensemble_matches_seq_sampler():
     assert np.all(np.abs(dev_mean - ref_mean) <= 5 * np.sqrt(dev_se ** 2 + ref_se ** 2)), (dev_mean, ref_mean, dev_se, ref_se)
 
 
+def test_eurus_sghmc_extension():
+    """BASELINE config 5 as it is worded (SGHMC with the Poyiadjis O(N) filter on the EURUS segments,
+    N = 10000): SGHMC is an extension (the reference has no momentum sampler), so it is pinned only by
+    construction -- friction 1 IS the SGLD trajectory, bit for bit -- and by staying finite and distinct."""
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.models.svm import SVMParameters
+    g, segs = eurus_segments()
+    th = g["theta0"]
+    p = SVMParameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+
+    def run(sampler, friction):
+        e = ChainEnsemble("svm", segs, p, num_chains=64, N=10000, epsilon=0.001, subsequence_length=16, buffer_length=4,
+                          seed=9, sampler=sampler, friction=friction)
+        e.step(3)
+        e.synchronize()
+        return e.theta()
+    sgld, hmc1, hmc = run("sgld", 1.0), run("sghmc", 1.0), run("sghmc", 0.1)
+    np.testing.assert_array_equal(sgld, hmc1)
+    assert np.all(np.isfinite(hmc)) and not np.array_equal(hmc, sgld)
+    assert np.all(np.abs(hmc[:, 0]) <= 0.9999 + 1e-12) and np.all(hmc[:, 1:] > 0)      # projection applied
+
+
 def test_device_generator_runs_are_a_function_of_np_random_state():
     """rng='device' through the Sampler API: seed AND stream of the device generator come from
     np.random, so np.random.seed(s) reproduces a run within one process (and across processes)."""
