@@ -35,7 +35,7 @@ _ONLY_PF = ("only kind='pf' is implemented by the MI355X backend; kind='{0}' (an
 # ----------------------------------------------------------------------------------------
 # window sampling (sgmcmc_sampler.py:1969-2017)
 # ----------------------------------------------------------------------------------------
-def random_subsequence_and_weights(S, T, partition_style=None):
+def random_subsequence_and_weights(S, T, partition_style=None, random_state=None):
     """Draw a length-S window of a length-T series and the importance weights that make the
     windowed sum unbiased for the full sum.  Consumes one np.random integer draw.
 
@@ -43,13 +43,14 @@ def random_subsequence_and_weights(S, T, partition_style=None):
     'strict': T % S == 0, start in {0,S,2S,..}; weights T/S.   'naive': weights T/S.
     Returns (start, end, weights[S])."""
     style = 'uniform' if partition_style is None else partition_style
+    rs = np.random if random_state is None else random_state
     if style == 'strict':
         if T % S != 0:
             raise ValueError("S {0} does not evenly divide T {1}".format(S, T))
-        start = np.random.choice(np.arange(0, T // S)) * S
+        start = rs.choice(np.arange(0, T // S)) * S
         weights = np.ones(S, dtype=float) * T / S
     elif style == 'uniform':
-        start = np.random.randint(0, T - S + 1)
+        start = rs.randint(0, T - S + 1)
         t = np.arange(start, start + S)
         cap = np.ones_like(t) * min(S, T - S + 1)
         if start + S <= 2 * S:
@@ -60,7 +61,7 @@ def random_subsequence_and_weights(S, T, partition_style=None):
             covering = np.ones(S) * S
         weights = np.ones(S, dtype=float) * (T - S + 1) / covering
     elif style == 'naive':
-        start = np.random.randint(0, T - S + 1)
+        start = rs.randint(0, T - S + 1)
         weights = np.ones(S, dtype=float) * T / S
     else:
         raise ValueError("Unrecognized partition_style = '{0}'".format(style))
@@ -242,7 +243,7 @@ class SGMCMCSampler(object):
         return T
 
     # -- windows -------------------------------------------------------------------------------
-    def _random_subsequence_and_buffers(self, buffer_length, subsequence_length, T=None):
+    def _random_subsequence_and_buffers(self, buffer_length, subsequence_length, T=None, random_state=None):
         """Window [start,end) plus up to buffer_length extra points each side
         (sgmcmc_sampler.py:259-288)."""
         if T is None:
@@ -253,7 +254,8 @@ class SGMCMCSampler(object):
             start, end, weights = 0, T, None
         else:
             start, end, weights = random_subsequence_and_weights(
-                S=subsequence_length, T=T, partition_style=self.options.get('partition_style'))
+                S=subsequence_length, T=T, partition_style=self.options.get('partition_style'),
+                random_state=random_state)
         return dict(subsequence_start=start, subsequence_end=end,
                     left_buffer_start=max(0, start - buffer_length),
                     right_buffer_end=min(T, end + buffer_length), weights=weights)
@@ -366,6 +368,7 @@ class SGMCMCSampler(object):
         for q in flat:
             if q["smoother"] == "filter":
                 raise ValueError("pf = 'filter' cannot be used for gradients")
+        self._speculate_next_stream(flat)
         outs = iter(_pf.run_windows(flat))
         grad = None
         for group in groups:
@@ -383,7 +386,37 @@ class SGMCMCSampler(object):
         return grad
 
     def _noisy_grad_loglikelihood(self, **kwargs):
+        self._last_grad_kwargs = kwargs
         return self._run_grad_problems([self._grad_problems(**kwargs)])
+
+    # what the step functions draw from np.random between this gradient and the next one's streams; set by
+    # sample_sgld / step_sgd / step_adagrad around their noisy_gradient call, None = do not speculate
+    _rng_after_gradient = None
+
+    def _speculate_next_stream(self, flat):
+        """While the GPU runs this window, prefetch the next one's replay stream on a worker thread
+        (particle_filters.speculation): same step type, same kwargs assumed; adopted only if np.random is
+        then bit for bit where the clone was, so a wrong guess costs nothing but the worker's time."""
+        after = self._rng_after_gradient
+        kw = getattr(self, "_last_grad_kwargs", None)
+        if (after is None or kw is None or len(flat) != 1 or flat[0].get("rng") != "replay"
+                or "_stream_bufs" not in flat[0] or type(self)._grad_groups is not SGMCMCSampler._grad_groups
+                or kw.get("buffer_dicts") is not None or kw.get("minibatch_size", 1) != 1):
+            return
+        N = int(flat[0]["N"])
+        T = self._get_observations(kw.get("observations"), check_shape=False).shape[0]
+        S, B = kw.get("subsequence_length", -1), kw.get("buffer_length", 0)
+        if N * int(flat[0]["y"].shape[0]) < _pf._SPECULATE_MIN:
+            return                                    # short windows: not worth a thread
+        shapes = [np.shape(v) for v in self.parameters.as_dict().values()] if after == "noise" else []
+
+        def between(rs):
+            for shp in shapes:                        # _get_sgmcmc_noise: one legacy normal per element
+                rs.normal(loc=0.0, scale=1.0, size=shp)
+            bd = self._random_subsequence_and_buffers(buffer_length=B, subsequence_length=S, T=T, random_state=rs)
+            return N, bd['right_buffer_end'] - bd['left_buffer_start']
+
+        _pf.speculation.start(between)
 
     def noisy_gradient(self, preconditioner=None, is_scaled=True, **kwargs):
         """grad log-likelihood (particle filter, buffered) + grad log-prior, optionally / T
@@ -457,7 +490,11 @@ class SGMCMCSampler(object):
 
     # -- steps ---------------------------------------------------------------------------------------
     def step_sgd(self, epsilon, **kwargs):
-        delta = self.noisy_gradient(**kwargs)
+        self._rng_after_gradient = "nothing"
+        try:
+            delta = self.noisy_gradient(**kwargs)
+        finally:
+            self._rng_after_gradient = None
         for var in self.parameters.var_dict:
             self.parameters.var_dict[var] += epsilon * delta[var]
         return self.parameters
@@ -465,7 +502,11 @@ class SGMCMCSampler(object):
     def step_adagrad(self, epsilon, **kwargs):
         if not hasattr(self, "_adagrad_moments"):
             self._adagrad_moments = dict(t=0, G=0.0)
-        g = self.parameters.from_dict_to_vector(self.noisy_gradient(**kwargs))
+        self._rng_after_gradient = "nothing"
+        try:
+            g = self.parameters.from_dict_to_vector(self.noisy_gradient(**kwargs))
+        finally:
+            self._rng_after_gradient = None
         G = self._adagrad_moments['G'] + g ** 2
         delta = self.parameters.from_vector_to_dict(g / np.sqrt(G + NOISE_NUGGET), **self.parameters.dim)
         for var in self.parameters.var_dict:
@@ -485,7 +526,11 @@ class SGMCMCSampler(object):
         """theta += eps * noisy_gradient + sqrt(2 eps) * N(0, 1/T)  (sgmcmc_sampler.py:549-567)."""
         if "preconditioner" in kwargs:
             raise ValueError("Use SGRLD instead")
-        delta = self.noisy_gradient(**kwargs)
+        self._rng_after_gradient = "noise"
+        try:
+            delta = self.noisy_gradient(**kwargs)
+        finally:
+            self._rng_after_gradient = None
         white_noise = self._get_sgmcmc_noise(**kwargs)
         for var in self.parameters.var_dict:
             self.parameters.var_dict[var] += epsilon * delta[var] + np.sqrt(2.0 * epsilon) * white_noise[var]

@@ -213,6 +213,51 @@ def test_seq_sampler_and_minibatch_match_reference(oracle_backend, golden_sample
     _check_seq_and_minibatch(golden_sampler, model, exact=True)
 
 
+def test_replay_stream_prefetch_is_adopted_and_exact(oracle_backend, golden_sampler, monkeypatch):
+    """The next step's replay stream is prefetched on a worker thread while the current window runs
+    (particle_filters.speculation) and adopted only when np.random is bit for bit where the clone was:
+    trajectories equal the reference's (same fixtures as above) AND the prefetch really is used; any other
+    use of np.random between steps voids it without changing a single number."""
+    g = golden_sampler
+    spec = particle_filters.speculation
+    monkeypatch.setattr(particle_filters, "_SPECULATE_MIN", 1000)      # the fixtures' windows are small
+    for meta in [m for m in g.meta if m["model"] == "svm" and m["pf"] == "poyiadjis_N"]:
+        y = g["svm/y"].reshape(-1, 1)
+        kwargs = dict(kind="pf", pf="poyiadjis_N", N=meta["N"], subsequence_length=meta["S"],
+                      buffer_length=meta["B"], minibatch_size=1)
+        sampler = SVMSampler(n=1, m=1, observations=y, parameters=default_params("svm"))
+        spec.cancel()                                   # a prefetch left over from an earlier loop
+        a0, d0 = spec.adopted, spec.discarded
+        np.random.seed(meta["seed"] + 1)
+        traj = [sampler.parameters.theta()]
+        for _ in range(meta["nsteps"]):
+            sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+            traj.append(sampler.parameters.theta())
+            sampler.project_parameters()
+            traj.append(sampler.parameters.theta())
+        np.testing.assert_array_equal(np.array(traj), g[meta["key"] + "/sgld_traj"])
+        assert spec.adopted - a0 == meta["nsteps"] - 1 and spec.discarded == d0
+        # something else draws from np.random between two steps: the prefetch is void, the numbers are not
+        spec.cancel()
+        sampler = SVMSampler(n=1, m=1, observations=y, parameters=default_params("svm"))
+        np.random.seed(5)
+        sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+        extra = np.random.normal()
+        d1 = spec.discarded
+        sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+        got = sampler.parameters.theta()
+        assert spec.discarded == d1 + 1
+        spec.cancel()
+        sampler = SVMSampler(n=1, m=1, observations=y, parameters=default_params("svm"))
+        np.random.seed(5)
+        sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+        spec.cancel()                                   # no prefetch at all this time
+        assert np.random.normal() == extra
+        sampler.sample_sgld(epsilon=meta["eps"], **kwargs)
+        np.testing.assert_array_equal(got, sampler.parameters.theta())
+    spec.cancel()
+
+
 def eurus_segments():
     """BASELINE config 5's data: the 49 gap-split EUR/USD hourly segments of the reference's demo
     (tests/golden/eurus.npz, data arrays + reference outputs; tests/golden/make_golden.py)."""
