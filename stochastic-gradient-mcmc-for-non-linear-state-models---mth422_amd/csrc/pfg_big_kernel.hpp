@@ -38,7 +38,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     constexpr int CH2 = NP2 / NT;                                   // CDF positions per thread (4 | 16)
     static_assert(CH2 == 4 || CH2 == 16, "NP2 must be 4096 or 16384");
     static_assert(CH2 * NW <= 4 * WAVE, "the (chunk, wave) totals are prefix-summed 4 per lane by one wave");
-    constexpr int G = 2;                                            // chunks in flight
+#ifndef PFG_BIG_G
+#define PFG_BIG_G 2
+#endif
+    constexpr int G = PFG_BIG_G;                                    // chunks in flight
     // NP2 = 4096, f32 state: a thread's (<= 4) log-weights never leave its registers (it is the only
     // reader and writer of its particles' weights): 8 of the 40 B per particle-step stay out of
     // memory (measured 8.66 -> 7.53 ms per 256 windows of N = 4000).  In fp64 the 8 extra VGPRs
@@ -290,7 +293,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
                         if (P.trace_x && P.rec_ud && v[g]) P.rec_ud[(size_t)t * N + i[g]] = u[g];
                     }
                 }
-                mth.normal_pair(rng.next(), rng.next(), z[0], z[1]);
+#pragma unroll
+                for (int g = 0; g < G; g += 2) mth.normal_pair(rng.next(), rng.next(), z[g], z[g + 1]);
                 if (P.trace_x && P.rec_z) {           // test instrumentation (see pfg_result.rec_z)
 #pragma unroll
                     for (int g = 0; g < G; ++g)
