@@ -189,7 +189,7 @@ def legacy_streams(random_state, N, T, z0, u, z, threads=0):
     for  z0 = normal(size=N); for t: u[t] = random_sample(N); z[t] = normal(size=N)  -- natively, bit for
     bit -- and advance its state accordingly."""
     lib = load_library()
-    rs = np.random.mtrand._rand if random_state is np.random else random_state
+    rs = random_state            # np.random (module: get_state / set_state act on the global generator) or a RandomState
     name, key, pos, has_gauss, gauss = rs.get_state()
     if name != "MT19937":
         raise ValueError("legacy streams need an MT19937 RandomState")
