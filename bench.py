@@ -56,11 +56,13 @@ RNG_PRECISION = ("device generator: xoshiro128++ per lane keyed by Philox4x32-10
 
 CONFIGS = {
     # name: (model, T_series, N, S, B, chains/GPU, description)
+    # chains/GPU: enough resident windows to amortise the launch's fixed cost (measured for c2: kernel time =
+    # 1.0 ms + 4.83 ms per 1024 chains, i.e. 194 k steps/s at 3072 chains, 207 k at 12288, 212 k asymptotically)
     "c1": ("lgssm", 200, 100, -1, -1, 16384, "LGSSM d=1 synthetic T=200 N=100, SGLD full sequence, optimal kernel (BASELINE configs[0])"),
-    "c2": ("svm", 1000, 1000, -1, -1, 3072, "SVM synthetic T=1000 N=1000, SGLD full sequence (S=-1), poyiadjis_N, prior kernel (BASELINE configs[1])"),
+    "c2": ("svm", 1000, 1000, -1, -1, 12288, "SVM synthetic T=1000 N=1000, SGLD full sequence (S=-1), poyiadjis_N, prior kernel (BASELINE configs[1])"),
     "c3": ("garch", 1000, 1000, 16, 4, 16384, "GARCH synthetic T=1000 N=1000, SGLD buffered PF S=16 B=4, poyiadjis_N, optimal kernel (BASELINE configs[2])"),
-    "c4": ("svm", 1000, 4000, -1, -1, 256, "SVM synthetic T=1000 N=4000, SGLD full sequence, poyiadjis_N (BASELINE configs[3], saturating variant)"),
-    "c5": ("svm", None, 10000, 16, 4, 512, "EURUS hourly log returns x1000, 49 gap-split segments, SeqSVM N=10000 S=16 B=4 num_sequences=1 (BASELINE configs[4])"),
+    "c4": ("svm", 1000, 4000, -1, -1, 512, "SVM synthetic T=1000 N=4000, SGLD full sequence, poyiadjis_N (BASELINE configs[3], saturating variant)"),
+    "c5": ("svm", None, 10000, 16, 4, 2048, "EURUS hourly log returns x1000, 49 gap-split segments, SeqSVM N=10000 S=16 B=4 num_sequences=1 (BASELINE configs[4])"),
 }
 STATE_STAT = {"svm": (1, 3), "garch": (2, 4), "lgssm": (1, 4)}
 
