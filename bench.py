@@ -409,7 +409,10 @@ def main():
         return ChainEnsemble(model, w["y"], w["p0"], num_chains=chains, N=w["N"], pf="poyiadjis_N", kernel=w["kernel"],
                              epsilon=w["epsilon"], prior=w["prior"], subsequence_length=w["S"], buffer_length=w["B"],
                              dtype=args.dtype, seed=seed, chain_offset=offset, device=dev_index,
-                             sampler=args.sampler, friction=0.1)
+                             sampler=args.sampler, friction=0.1,
+                             # buffered windows of ONE series are drawn on the device (no host work per step);
+                             # sequence lists (c5) still sample on the host
+                             window_sampling=("device" if w["S"] != -1 and not isinstance(w["y"], list) else "host"))
 
     ens = make_ensemble(C, 2024, lo)
     ens.enable_stamps()
@@ -425,7 +428,9 @@ def main():
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if ens.steps_done > 0 and ens._set_windows():
+        if ens.window_sampling == "device":
+            ens.launch_windows(stream)
+        elif ens.steps_done > 0 and ens._set_windows():
             ens.desc_dev.copy_(torch.from_numpy(ens._desc.view(np.uint8).reshape(ens.C, -1)), non_blocking=True)
         ev[k][0].record(stream)
         ens.launch_pf(stream)
