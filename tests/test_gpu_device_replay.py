@@ -83,6 +83,16 @@ CASES = [
     ("svm", "prior", "poyiadjis_N", 1.0, 9001, 30, None, "big16384", (16384, 1, "f64_uniform")),
     ("garch", "optimal", "poyiadjis_N", 1.0, 4000, 40, None, "big4096", (4096, 1, "f64_uniform")),
     ("lgssm", "optimal", "nemeth", 0.95, 3000, 40, None, "big4096", (4096, 1, "f64_uniform")),
+    # edges: every slot used, one slot used beyond a power of two, ragged N, a single timestep, the maximum N
+    ("svm", "prior", "poyiadjis_N", 1.0, 1024, 60, None, "wg256x4s", (256, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 129, 40, None, "wg256x1", (256, 1, "fixed32")),
+    ("lgssm", "prior", "poyiadjis_N", 1.0, 65, 30, None, "wg64x2", (64, 2, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 1000, 1, None, "wg256x4s", (256, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 4096, 20, None, "wg1024x4s", (1024, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 1025, 20, None, "wg1024x4s", (1024, 4, "fixed32")),
+    ("garch", "prior", "nemeth", 0.9, 4097, 12, (2, 9, True), "big16384", (16384, 1, "f64_uniform")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 16384, 6, None, "big16384", (16384, 1, "f64_uniform")),
+    ("lgssm", "optimal", "filter", 1.0, 1500, 10, None, "big4096", (4096, 1, "f64_uniform")),
 ]
 
 
