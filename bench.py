@@ -248,7 +248,11 @@ def valu_roofline(key, chains, kern_ms, clock_ghz):
     cycles = f64 * cost["f64"] + tr64 * cost["trans_f64"] + tr32 * cost["trans_f32"] + other * cost["b32"]
     achieved = cycles / (kern_ms * 1e-3) / 1e9             # G issue-cycles per second actually delivered
     peak = N_SIMD * clock_ghz                               # G issue-cycles per second available
+    mixed = cal.get("mixed_stream_cycles_per_wave_instruction_at_4_waves_per_simd", {}).get("f64_share_0.22")
     return dict(achieved=achieved, peak=peak, frac=achieved / peak,
+                # against a stall-free stream of the kernel's own fp64 / 32-bit mix (alternating the two costs
+                # issue slots: 2.89 instead of 2.20 cycles per instruction): the estimate, `frac` is the lower bound
+                frac_mixed_stream=(total * mixed / (kern_ms * 1e-3) / 1e9 / peak) if mixed else None,
                 valu_instructions_per_launch=total, fp64_arith_instructions_per_launch=f64,
                 issue_cycle_model=cost, counters_from="profiles/valu_issue.json:" + key,
                 in_kernel_clock_ghz=clock_ghz)

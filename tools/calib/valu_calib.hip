@@ -12,7 +12,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
-constexpr int UNROLL = 16;     // independent accumulators per lane
+constexpr int UNROLL = 18;     // independent accumulators per lane (18: two periods of the 2-in-9 mix)
 
 template <int KIND>
 __global__ __launch_bounds__(256) void stream_kernel(int iters, double *out, unsigned long long *cyc) {
@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void stream_kernel(int iters, double *out, uns
             if (KIND == 4) {   // alternate f64 / b32
                 if (j & 1) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a64[j]) : "v"(b64), "v"(c64));
                 else asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u32[j]) : "v"(u32[(j + 2) % UNROLL]));
+            }
+            if (KIND == 7) {   // the bench kernel's class mix: 22 % fp64 arithmetic, 78 % 32-bit (2 of every 9)
+                if (j % 9 == 2 || j % 9 == 6) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a64[j % 8]) : "v"(b64), "v"(c64));
+                else if (j & 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u32[j]) : "v"(u32[(j + 3) % UNROLL]));
+                else asm volatile("v_add_u32 %0, %0, %1" : "+v"(u32[j]) : "v"(u32[(j + 5) % UNROLL]));
             }
             if (KIND == 5) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a64[j]) : "v"(c64));
             if (KIND == 6) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a64[j]) : "v"(b64));
@@ -101,6 +106,7 @@ int main(int argc, char **argv) {
         run<2>("v_exp_f32", w, iters);
         run<3>("v_xor_b32", w, iters);
         run<4>("f64:b32 1:1", w, iters);
+        run<7>("f64:b32 2:7", w, iters);
     }
     return 0;
 }
