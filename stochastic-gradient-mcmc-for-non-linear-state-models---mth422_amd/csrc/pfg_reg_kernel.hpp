@@ -68,7 +68,10 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // maximum only on underflow: SVM +10 %, GARCH 0 % -- the retry path costs 9 more spilled registers); the
 // step's words / normals drawn behind barrier 2, next to the serial offsets chain (+10 %: 4-8 more live
 // registers); search levels 1-3 compared in registers against 7 broadcast pivots (7 instead of 10 dependent
-// LDS round trips: 0 % -- the search is issue-bound, not LDS-latency-bound).
+// LDS round trips: 0 % -- the search is issue-bound, not LDS-latency-bound); fewer, wider threads for the same
+// four LDS-bound workgroups per CU (128 threads x 8 particles at 2 waves per SIMD and 227 VGPRs, no spills:
+// +18 %; 64 x 16 at one wave per SIMD, no barriers left: +51 %) -- thread-level parallelism hides the LDS and
+// fp64 latencies better than the same independent work inside one wave.
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
