@@ -279,7 +279,10 @@ template <> struct Math<double, true> {
     __device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &z0, float &z1) const {
         const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;       // (0, 1]
         const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);             // [0,1): angle / 2pi
-        const float r = sqrtf(-2.0f * __logf(u1));
+        // raw v_log_f32 / v_sqrt_f32 (1 ulp each; u1 >= 2^-33 is a normal number, the radicand is in [0, 46]):
+        // the library logf / sqrtf add a denormal rescue, an extended-precision ln 2 product and a
+        // correctly-rounded-sqrt fix-up, ~20 instructions per pair that a 24-bit normal has no use for
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
         z0 = r * __builtin_amdgcn_cosf(u2);
         z1 = r * __builtin_amdgcn_sinf(u2);
     }
@@ -317,7 +320,7 @@ template <bool TAB> struct Math<float, TAB> {
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) const {
         const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1), 24 bits
         const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi
-        const float r = sqrtf(-2.0f * __logf(u1));
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // raw units, see Math<double, true>
         // v_sin_f32 / v_cos_f32 take their argument in revolutions
         z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
     }

@@ -468,17 +468,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 for (int k = 0; k < PPT; ++k)
                     if (valid[k]) P.rec_u[(size_t)t * N + k * NT + tid] = ua[k];
             }
+            // the search runs on BYTE offsets into the CDF (the LDS address itself: probe offsets fold into the
+            // ds_read immediates and a level costs compare + select + add, no address arithmetic)
+            using lds_u32 = const __attribute__((address_space(3))) uint32_t;
+            const uint32_t cdf_base = (uint32_t)(uintptr_t)(lds_u32 *)cdfu;
+            uint32_t off[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) off[k] = cdf_base;
 #pragma unroll
             for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
                 const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
                 const int adv = step + (step >> 5);
+                uint32_t cv[PPT];
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) anc[k] += (cdfu[anc[k] + probe] <= ua[k]) ? adv : 0;
+                for (int k = 0; k < PPT; ++k) cv[k] = *(lds_u32 *)(uintptr_t)(off[k] + 4u * probe);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) off[k] += (cv[k] <= ua[k]) ? 4u * adv : 0u;
             }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                anc[k] -= (anc[k] * 993) >> 15;                                 // physical -> CDF position
-                anc[k] = (anc[k] & (PPT - 1)) * NT + (anc[k] >> LOG_PPT);       // -> particle index
+                uint32_t p = (off[k] - cdf_base) >> 2;
+                p -= __umul24(p, 993u) >> 15;                                   // physical -> CDF position (p < 2^15)
+                anc[k] = (int)(((p << (NT == 256 ? 8 : (NT == 1024 ? 10 : 6))) & (uint32_t)((PPT - 1) * NT)) | (p >> LOG_PPT));   // -> particle index
             }
         } else if (FAST) {
             // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
@@ -537,34 +548,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         if (valid[k]) P.rec_z[(size_t)t * N + k * NT + tid] = (double)zz[k];
                 }
             }
+            // One straight-line block per case: the case is uniform, so it is decided once per timestep and
+            // not per particle, and the stores of a FAST layout are unconditional (a slot beyond N has its own
+            // LDS cell and weight 0) -- the PPT particle chains stay in one basic block for the scheduler.
+            auto children = [&](auto upd_tag) {
+                constexpr int UPD = decltype(upd_tag)::value;      // 0 plain + statistic, 1 plain, no statistic, 2 general
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                REAL xn[NS], add[H], lwn;
-                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
-                lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
-                if (plain) {
-                    // Poyiadjis O(N), lambda = 1: 1*s[a] + 0*S + w_t h = s[a] + w_t h exactly
-                    if (use_stat) {
+                for (int k = 0; k < PPT; ++k) {
+                    REAL xn[NS], add[H], lwn;
+                    particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp[k], (REAL)y_t, zz[k], xn, lwn, add);
+                    lw[k] = valid[k] ? lwn : (REAL)(-INFINITY);
+                    if (UPD == 0) {
+                        // Poyiadjis O(N), lambda = 1: 1*s[a] + 0*S + w_t h = s[a] + w_t h exactly
 #pragma unroll
                         for (int h = 0; h < H; ++h) sp[k][h] = sp[k][h] + add[h] * (REAL)wt;
-                    }
-                } else {
+                    } else if (UPD == 2) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
-                        // pf.py:175-179 / :78-80
-                        const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
-                        sp[k][h] = is_filter ? a : sm;
+                        for (int h = 0; h < H; ++h) {
+                            const REAL a = use_stat ? add[h] * (REAL)wt : (REAL)0;
+                            // pf.py:175-179 / :78-80
+                            const REAL sm = (lam * sp[k][h] + oml * (REAL)S[h]) + a;
+                            sp[k][h] = is_filter ? a : sm;
+                        }
+                    }
+                    if (FAST || valid[k]) {
+                        const int i = k * NT + tid;
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sp[k][h];
                     }
                 }
-                if (valid[k]) {
-                    const int i = k * NT + tid;
-#pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
-#pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sp[k][h];
-                }
-            }
+            };
+            if (!plain) children(std::integral_constant<int, 2>{});
+            else if (use_stat) children(std::integral_constant<int, 0>{});
+            else children(std::integral_constant<int, 1>{});
         };
         // PaRIS (pf.py:183-341): children are proposed from the filter's ancestors as above, then
         // every child draws Ntilde parents from the backward kernel  w_k q(child | x_k)  by
