@@ -19,7 +19,7 @@ namespace pfg {
 __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (i >> 5); }
 // FAST layout = LDS math tables + sentinel-padded, bank-conflict-free cdf with an unrolled search.
 // Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
-__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 256 || NT == 1024; }
+__host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 512 || NT == 1024; }
 
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;
@@ -51,6 +51,7 @@ __host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP,
     return (NT >= 512 || NT == 64 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
 }
 __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
+    if (NT == 512) return 4;        // two 8-wave workgroups per CU
     return dev4 ? 4 : ((NT == 256 && PPT == 4 && !PP) ? 3 : 1);
 }
 // Device-generator units only (-DPFG_FAST_ALGEBRA; the REPLAY units keep the reference's operation
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) {
                 uint32_t p = (off[k] - cdf_base) >> 2;
                 p -= __umul24(p, 993u) >> 15;                                   // physical -> CDF position (p < 2^15)
-                anc[k] = (int)(((p << (NT == 256 ? 8 : (NT == 1024 ? 10 : 6))) & (uint32_t)((PPT - 1) * NT)) | (p >> LOG_PPT));   // -> particle index
+                anc[k] = (int)(((p << (NT == 256 ? 8 : (NT == 512 ? 9 : (NT == 1024 ? 10 : 6)))) & (uint32_t)((PPT - 1) * NT)) | (p >> LOG_PPT));   // -> particle index
             }
         } else if (FAST) {
             // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets

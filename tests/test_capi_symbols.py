@@ -45,7 +45,8 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(2, 1, 0, 1, 4096) == b"big4096"       # LGSSM fp64 (5 arrays) does not: fast large-N kernel
     assert lib.pfg_variant_name(2, 1, 1, 1, 4096) == b"wg1024x4s"     # ... in f32 it does
     assert lib.pfg_variant_name(0, 0, 0, 1, 10000) == b"big16384"
-    assert lib.pfg_variant_name(1, 1, 0, 1, 1000) == b"wg256x4s"      # GARCH fp64 (n=2, h=4) still LDS-resident
+    assert lib.pfg_variant_name(1, 1, 0, 1, 1000) == b"wg512x2s"      # GARCH fp64 (n=2, h=4) still LDS-resident: 8 waves
+    assert lib.pfg_variant_name(1, 1, 0, 0, 1000) == b"wg256x4s"      # ... the REPLAY units keep 256 x 4
     assert lib.pfg_variant_name(1, 1, 0, 0, 4000) == b"mem1024" and lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"big4096"
     assert lib.pfg_variant_name(0, 0, 0, 0, 10000) == b"mem1024" and lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"none"
     assert lib.pfg_scratch_bytes(0, 0, 1, 1000) == 0 and lib.pfg_scratch_bytes(0, 0, 1, 20000) == -1

@@ -74,8 +74,10 @@ CASES = [
     ("lgssm", "optimal", "poyiadjis_N", 1.0, 100, 200, None, "wg64x2", (64, 2, "fixed32")),
     ("lgssm", "prior", "nemeth", 0.9, 128, 50, None, "wg64x2", (64, 2, "fixed32")),
     # config 3: GARCH N=1000, S=16 B=4 window
+    ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg512x2s", (512, 2, "fixed32")),
+    ("garch", "prior", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg512x2s", (512, 2, "fixed32")),
+    ("garch", "optimal", "nemeth", 0.9, 1024, 40, None, "wg512x2s", (512, 2, "fixed32")),
     ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
-    ("garch", "prior", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
     # config 4: SVM N=4000, LDS-resident 1024 x 4
     ("svm", "prior", "poyiadjis_N", 1.0, 4000, 250, None, "wg1024x4s", (1024, 4, "fixed32")),
     # config 5: SVM N=10000, S=16 B=4 window, large-N kernel (fp64 CDF)
