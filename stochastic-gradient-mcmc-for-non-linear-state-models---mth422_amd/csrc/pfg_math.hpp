@@ -156,7 +156,7 @@ __device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream,
 // exponential spacing -log(u), u in (0, 1) with 24 random bits, on the f32 log unit (pf_big_kernel's sorted
 // resampling uniforms; an input of the filter like the Box-Muller normals)
 __device__ __forceinline__ float spacing_f32(uint32_t w) {
-    return -__logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f));
+    return -0.6931471805599453f * __builtin_amdgcn_logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f));   // raw v_log_f32: the argument is a normal number
 }
 
 // f64 -> u32, saturating at both ends (what v_cvt_u32_f64 does; a C cast is undefined out of range)

@@ -575,7 +575,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                             sp[k][h] = is_filter ? a : sm;
                         }
                     }
-                    if (FAST || valid[k]) {
+                    // (1024 threads: the guarded store keeps the particles in separate blocks -- 19 instead of 27
+                    // spilled registers at the 128-VGPR cap, 13.1 instead of 14.5 ms per config-4 launch)
+                    if ((FAST && NT < 1024) || valid[k]) {
                         const int i = k * NT + tid;
 #pragma unroll
                         for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
