@@ -23,13 +23,14 @@
 #ifndef PFGRAD_H
 #define PFGRAD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PFG_VERSION 110          /* 0.1.1 */
+#define PFG_VERSION 111          /* 0.1.11 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -288,6 +289,14 @@ int pfg_imq_ksd(pfg_ctx *ctx, int K, int d, const double *x, const double *g, do
  * The state is RandomState.get_state()'s (key[624], pos, has_gauss, cached_gaussian), advanced in place. */
 int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, int N, int T,
                        double *z0, double *u, double *z, int threads);
+
+/* Page-lock a caller-owned host buffer (hipHostRegister) so that pfg_run_batch stages it with a DMA straight
+ * from where it lies: an input array of a pfg_problem that falls inside a registered range skips the pack copy
+ * into the library's own pinned arena (the 2 x 8 MB replay streams of a T = N = 1000 window: 1.2 ms of a 5.6 ms
+ * step).  The buffer must stay allocated and registered until pfg_host_unregister; registering a range twice
+ * is an error.  Returns PFG_OK or a negative code (no message channel: there is no context here). */
+int pfg_host_register(void *ptr, size_t bytes);
+int pfg_host_unregister(void *ptr);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // The particle-filter kernels are instantiated in pfg_inst_*.hip (one unit per model x proposal
 // kernel, compiled in parallel by sgmcmc_ssm_amd/_build.py); this unit holds the dispatcher, the
 // small update / window / KSD kernels and the extern "C" entry points.
+#include <mutex>
 #include "pfg_host.hpp"
 #include "pfg_device.hpp"
 #include "pfg_elementwise.hpp"
@@ -332,9 +333,56 @@ int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *theta_dev
 // ======================================================================================
 // C ABI
 // ======================================================================================
+// ---- caller-registered pinned host ranges (pfg_host_register) -------------------------------------
+namespace {
+struct HostRange { const char *lo, *hi; };
+std::mutex g_host_mu;
+std::vector<HostRange> g_host_ranges;
+bool host_registered(const void *p, size_t bytes) {
+    const char *a = static_cast<const char *>(p);
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (const HostRange &r : g_host_ranges)
+        if (a >= r.lo && a + bytes <= r.hi) return true;
+    return false;
+}
+}  // namespace
+
 extern "C" {
 
 int pfg_version(void) { return PFG_VERSION; }
+
+int pfg_host_register(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return PFG_ERR_INVALID;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        const char *a = static_cast<const char *>(ptr);
+        for (const HostRange &r : g_host_ranges)
+            if (a < r.hi && a + bytes > r.lo) return PFG_ERR_INVALID;      // overlaps a registered range
+    }
+    if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return PFG_ERR_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_ranges.push_back({static_cast<const char *>(ptr), static_cast<const char *>(ptr) + bytes});
+    return PFG_OK;
+}
+
+int pfg_host_unregister(void *ptr) {
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_ranges.begin();
+        for (; it != g_host_ranges.end(); ++it)
+            if (it->lo == static_cast<const char *>(ptr)) break;
+        if (it == g_host_ranges.end()) return PFG_ERR_INVALID;
+        g_host_ranges.erase(it);
+    }
+    if (hipHostUnregister(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return PFG_ERR_DEVICE;
+    }
+    return PFG_OK;
+}
 
 int pfg_struct_size(int which) {
     switch (which) {
@@ -641,9 +689,14 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     const double *din = static_cast<const double *>(ctx->in.ptr);
     double *dout = static_cast<double *>(ctx->out.ptr);
     size_t oi = 0, oo = 0;
+    // big inputs that lie in caller-registered pinned memory (pfg_host_register) go to the device straight
+    // from there; everything else is packed into the library's pinned arena and staged in one copy
+    struct Direct { size_t at; const double *src; size_t n; };
+    std::vector<Direct> direct;
     auto put = [&](const double *src, size_t n) -> const double * {
         if (!src || n == 0) return nullptr;
-        std::memcpy(hin + oi, src, n * 8);
+        if (n >= (size_t)(1 << 16) && host_registered(src, n * 8)) direct.push_back({oi, src, n});
+        else std::memcpy(hin + oi, src, n * 8);
         const double *d = din + oi;
         oi += n;
         return d;
@@ -737,7 +790,20 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     }
 
     // ---- stage, launch, fetch -----------------------------------------------------------
-    PFG_HIP(ctx, hipMemcpyAsync(ctx->in.ptr, hin, oi * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (direct.empty()) {
+        PFG_HIP(ctx, hipMemcpyAsync(ctx->in.ptr, hin, oi * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        // the packed pieces between the direct ones, then the direct ones from the caller's pinned pages
+        size_t at = 0;
+        for (const Direct &dd : direct) {
+            if (dd.at > at)
+                PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + at, hin + at, (dd.at - at) * 8, hipMemcpyHostToDevice, ctx->stream));
+            PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + dd.at, dd.src, dd.n * 8, hipMemcpyHostToDevice, ctx->stream));
+            at = dd.at + dd.n;
+        }
+        if (oi > at)
+            PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + at, hin + at, (oi - at) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     PFG_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->h_desc.data(), (size_t)B * sizeof(pfg_dev_problem),
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));

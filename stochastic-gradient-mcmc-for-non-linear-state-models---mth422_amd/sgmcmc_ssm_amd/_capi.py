@@ -93,7 +93,7 @@ DEV_PROBLEM_DTYPE = np.dtype([
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
-           "pfg_last_variant", "pfg_legacy_streams")
+           "pfg_last_variant", "pfg_legacy_streams", "pfg_host_register", "pfg_host_unregister")
 
 _lib = None
 
@@ -162,6 +162,10 @@ def load_library():
     lib.pfg_legacy_streams.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.pfg_legacy_streams.restype = C.c_int
+    lib.pfg_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.pfg_host_register.restype = C.c_int
+    lib.pfg_host_unregister.argtypes = [C.c_void_p]
+    lib.pfg_host_unregister.restype = C.c_int
     lib.pfg_last_variant.argtypes = [C.c_void_p]
     lib.pfg_last_variant.restype = C.c_char_p
     lib.pfg_synchronize.argtypes = [C.c_void_p]
@@ -204,6 +208,16 @@ def legacy_streams(random_state, N, T, z0, u, z, threads=0):
     if rc != 0:
         raise PfgError(rc, "pfg_legacy_streams failed")
     rs.set_state((name, key, pos_c.value, hg_c.value, g_c.value))
+
+
+def host_register(a):
+    """Page-lock the ndarray `a` (pfg_host_register): pfg_run_batch then stages it by DMA from where it lies.
+    The caller keeps `a` alive until host_unregister(a).  Returns False when the runtime refuses (no GPU, limits)."""
+    return load_library().pfg_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+
+
+def host_unregister(a):
+    return load_library().pfg_host_unregister(a.ctypes.data_as(C.c_void_p)) == 0
 
 
 def _as_f64(a):

@@ -52,11 +52,34 @@ _stream_pool = {}
 _STREAM_POOL_MAX_BYTES = 512 << 20
 
 
+# Large stream buffers are page-locked once (pfg_host_register) and then live in the pool for the rest of the
+# process -- registered pages must never go back to the allocator -- so that pfg_run_batch stages them by DMA
+# from where the generator wrote them instead of copying 16 MB into its own pinned arena first.
+_PIN_MIN_BYTES = 1 << 20
+_PIN_MAX_BYTES = 256 << 20
+_pinned = []                   # (u, z) pairs kept alive for good
+_pinned_bytes = 0
+
+
 def _stream_buffers(N, T):
     free = _stream_pool.get((N, T))
     if free:
         return free.pop()
-    return np.empty((T, N)), np.empty((T, N))
+    global _pinned_bytes
+    u, z = np.empty((T, N)), np.empty((T, N))
+    if u.nbytes >= _PIN_MIN_BYTES and _pinned_bytes + 2 * u.nbytes <= _PIN_MAX_BYTES:
+        u.fill(0.0); z.fill(0.0)           # touch the pages before locking them
+        if _capi.host_register(u):
+            if _capi.host_register(z):
+                _pinned.append((u, z))
+                _pinned_bytes += 2 * u.nbytes
+            else:
+                _capi.host_unregister(u)
+    return u, z
+
+
+def _is_pinned(bufs):
+    return any(bufs[0] is p[0] for p in _pinned)
 
 
 def _recycle_streams(problems):
@@ -64,7 +87,7 @@ def _recycle_streams(problems):
     held = sum(len(v) * 2 * k[0] * k[1] * 8 for k, v in _stream_pool.items())
     for q in problems:
         bufs = q.pop("_stream_bufs", None)
-        if bufs is not None and held < _STREAM_POOL_MAX_BYTES:
+        if bufs is not None and (held < _STREAM_POOL_MAX_BYTES or _is_pinned(bufs)):
             _stream_pool.setdefault(bufs[0].shape[::-1], []).append(bufs)
             held += 2 * bufs[0].nbytes
 

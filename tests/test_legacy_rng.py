@@ -34,6 +34,25 @@ def test_native_streams_bit_identical(N, T, seed, pre, threads):
     assert a.randint(0, 1000) == b.randint(0, 1000)
 
 
+@pytest.mark.parametrize("N,T,seed,pre,threads", [
+    (1000, 1000, 21, 0, 0), (999, 130, 22, 1, 2), (64, 2000, 23, 3, 0), (17, 7001, 24, 0, 4), (100000, 1, 25, 1, 0),
+    (1250, 81, 26, 2, 16)])
+def test_pipelined_generator_bit_identical(N, T, seed, pre, threads):
+    """Streams long enough for the pipelined path (recurrence on a producer thread, transforms on workers):
+    same numbers, same final state, also over two calls in a row."""
+    a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+    for _ in range(pre):
+        a.normal(); b.normal(); a.random_sample(3); b.random_sample(3)
+    for rep in range(2):
+        ref = numpy_streams(a, N, T)
+        z0, u, z = np.empty(N), np.empty((T, N)), np.empty((T, N))
+        _capi.legacy_streams(b, N, T, z0, u, z, threads=threads)
+        assert np.array_equal(ref[0], z0) and np.array_equal(ref[1], u) and np.array_equal(ref[2], z)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    assert a.normal() == b.normal() and np.array_equal(a.random_sample(4), b.random_sample(4))
+
+
 def test_global_np_random_and_draw_replay_streams():
     N, T = 80, 100                        # N * T above the native threshold
     np.random.seed(5)

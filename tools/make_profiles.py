@@ -60,3 +60,23 @@ for c in cfgs:
           "bench kernel_ms:", line["roofline"]["kernel_ms"], "traffic MB:", traffic.get(key, {}).get("bytes_per_launch", 0) / 1e6)
 json.dump(valu, open(os.path.join(PROF, "valu_issue.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(PROF, "hbm_traffic.json"), "w"), indent=1)
+
+# The traced run computed its roofline from the counters committed BEFORE it; restate it with the counters of
+# these very passes so that profiles/<tag>_<config>_bench.json agrees with valu_issue.json / hbm_traffic.json.
+sys.path.insert(0, ROOT)
+import bench
+for c in cfgs:
+    p = os.path.join(PROF, "{0}_{1}_bench.json".format(tag, c))
+    line = json.load(open(p))
+    variant, chains, dtype = line["config"]["kernel_variant"], line["config"]["chains_per_gpu"], line["dtype"]
+    key = "{0}_{1}_{2}".format(c, dtype, variant)
+    roof = line["roofline"]
+    if key in traffic:
+        roof["traffic"] = traffic[key]["bytes_per_launch"] * chains / traffic[key]["chains"]
+    if roof.get("bound") == "valu":
+        vr = bench.valu_roofline(key, chains, roof["kernel_ms"], roof["in_kernel_clock_ghz"])
+        if vr:
+            roof.update(achieved=vr["achieved"], peak=vr["peak"], frac=vr["frac"], valu=vr)
+    roof["counters"] = "restated by tools/make_profiles.py with the PMC passes of this same profile run"
+    json.dump(line, open(p, "w"), indent=1)
+    print(c, "roofline", roof["bound"], round(roof["frac"], 3), (round(roof["valu"]["frac_mixed_stream"], 3) if roof.get("valu") else ""))
