@@ -11,9 +11,12 @@
 // Algorithms restated from their published definitions: MT19937 (Matsumoto & Nishimura 1998), the
 // 53-bit double (a >> 5, b >> 6), Marsaglia's polar method with the second variate cached.
 // Host-only translation unit, compiled with -ffp-contract=off (x1*x1 + x2*x2 must not be fused).
+#include <atomic>
 #include <cmath>
+#include <immintrin.h>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -97,13 +100,73 @@ struct MT {
     }
 };
 
-// one accepted attempt of the polar method, transform still to do
-struct Pair { double x1, x2, r2; };
+// one accepted attempt of the polar method: (x1, x2, r2), transform still to do
+inline void transform(double x1, double x2, double r2, double &first, double &second) {
+    const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+    first = f * x2;          // returned by this call
+    second = f * x1;         // cached for the next call
+}
 
-inline void transform(const Pair &p, double &first, double &second) {
-    const double f = std::sqrt(-2.0 * std::log(p.r2) / p.r2);
-    first = f * p.x2;          // returned by this call
-    second = f * p.x1;         // cached for the next call
+// Acceptance, in order: copy the attempts with 0 < r2 < 1 to the front of (o1, o2, o3), stop after `want`
+// accepted ones.  Returns the number of attempts consumed; `got` = accepted.  The destination needs 4 doubles
+// of slack behind the last accepted entry (vector stores).
+inline int accept_generic(const double *c1, const double *c2, const double *c3, int n, size_t want,
+                          double *o1, double *o2, double *o3, size_t &got) {
+    int used = 0;
+    got = 0;
+    while (used < n && got < want) {                      // branch-free: a rejected attempt is overwritten
+        const double r2 = c3[used];
+        o1[got] = c1[used]; o2[got] = c2[used]; o3[got] = r2;
+        got += (r2 >= 1.0 || r2 == 0.0) ? 0 : 1;
+        ++used;
+    }
+    return used;
+}
+
+__attribute__((target("avx2"))) int accept_avx2(const double *c1, const double *c2, const double *c3, int n, size_t want,
+                                                double *o1, double *o2, double *o3, size_t &got) {
+    // left-pack permutation (pairs of 32-bit lanes) for every 4-bit acceptance mask
+    alignas(32) static const int32_t LUT[16][8] = {
+        {0, 1, 2, 3, 4, 5, 6, 7}, {0, 1, 2, 3, 4, 5, 6, 7}, {2, 3, 0, 1, 4, 5, 6, 7}, {0, 1, 2, 3, 4, 5, 6, 7},
+        {4, 5, 0, 1, 2, 3, 6, 7}, {0, 1, 4, 5, 2, 3, 6, 7}, {2, 3, 4, 5, 0, 1, 6, 7}, {0, 1, 2, 3, 4, 5, 6, 7},
+        {6, 7, 0, 1, 2, 3, 4, 5}, {0, 1, 6, 7, 2, 3, 4, 5}, {2, 3, 6, 7, 0, 1, 4, 5}, {0, 1, 2, 3, 6, 7, 4, 5},
+        {4, 5, 6, 7, 0, 1, 2, 3}, {0, 1, 4, 5, 6, 7, 2, 3}, {2, 3, 4, 5, 6, 7, 0, 1}, {0, 1, 2, 3, 4, 5, 6, 7}};
+    const __m256d one = _mm256_set1_pd(1.0), zero = _mm256_setzero_pd();
+    int used = 0;
+    got = 0;
+    // whole groups of four while even four acceptances cannot overshoot `want`
+    while (used + 4 <= n && got + 4 <= want) {
+        const __m256d r = _mm256_loadu_pd(c3 + used);
+        // accepted <=> !(r2 >= 1.0 || r2 == 0.0)  (a NaN cannot occur: r2 is a sum of squares of finite numbers)
+        const __m256d rej = _mm256_or_pd(_mm256_cmp_pd(r, one, _CMP_GE_OQ), _mm256_cmp_pd(r, zero, _CMP_EQ_OQ));
+        const int m = (~_mm256_movemask_pd(rej)) & 15;
+        const __m256i idx = _mm256_load_si256(reinterpret_cast<const __m256i *>(LUT[m]));
+        _mm256_storeu_pd(o1 + got, _mm256_castsi256_pd(_mm256_permutevar8x32_epi32(_mm256_castpd_si256(_mm256_loadu_pd(c1 + used)), idx)));
+        _mm256_storeu_pd(o2 + got, _mm256_castsi256_pd(_mm256_permutevar8x32_epi32(_mm256_castpd_si256(_mm256_loadu_pd(c2 + used)), idx)));
+        _mm256_storeu_pd(o3 + got, _mm256_castsi256_pd(_mm256_permutevar8x32_epi32(_mm256_castpd_si256(r), idx)));
+        got += (size_t)__builtin_popcount((unsigned)m);
+        used += 4;
+    }
+    size_t tail = 0;
+    used += accept_generic(c1 + used, c2 + used, c3 + used, n - used, want - got, o1 + got, o2 + got, o3 + got, tail);
+    got += tail;
+    return used;
+}
+
+// Copy n doubles to a destination nobody reads again on this core (the stream arrays are consumed by the GPU's
+// DMA engine): whole cache lines go out with non-temporal stores, so the 16 MB of a T = N = 1000 window are
+// written once instead of read-for-ownership and written.
+__attribute__((target("avx2"))) void stream_copy_avx2(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
+    size_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 63u)) { dst[i] = src[i]; ++i; }
+    for (; i + 8 <= n; i += 8) {
+        _mm256_stream_pd(dst + i, _mm256_loadu_pd(src + i));
+        _mm256_stream_pd(dst + i + 4, _mm256_loadu_pd(src + i + 4));
+    }
+    for (; i < n; ++i) dst[i] = src[i];
+}
+inline void stream_copy(bool avx2, double *dst, const double *src, size_t n) {
+    if (avx2) stream_copy_avx2(dst, src, n); else std::memcpy(dst, src, n * sizeof(double));
 }
 
 }  // namespace
@@ -115,15 +178,92 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
     MT mt;
     mt.key = key; mt.pos = *pos;
     mt.init();
+    const bool avx2 = mt.avx2;
     // normals are consumed row after row: z0, z[0], z[1], ... with the cached second variate carried
     // across rows.  dst[k] is the k-th normal overall; pair q fills dst[2q + off], dst[2q + 1 + off].
     const size_t total = (size_t)N * ((size_t)T + 1);
-    std::vector<Pair> pairs;
-    try { pairs.resize(total / 2 + 2); } catch (...) { return PFG_ERR_NOMEM; }
-    auto dst = [&](size_t k) -> double * { return k < (size_t)N ? z0 + k : z + (k - N); };
-    size_t k = 0, npairs = 0;
     const bool lead_cached = *has_gauss != 0;       // the first normal comes from the cache
-    if (lead_cached) { *dst(0) = *gauss; k = 1; }
+    if (lead_cached) z0[0] = *gauss;
+    const size_t off = lead_cached ? 1 : 0;
+    double spill = 0.0;
+    bool spilled = false;
+
+    // The accepted attempts of a SLICE of rows wait in a small ring of buffers (cache resident) for their
+    // transform -- sqrt, log, divide per pair with the host libm NumPy calls -- which runs on worker threads
+    // behind the sequential word / acceptance loop (threads = 1: on this thread, slice by slice).
+    // Measured on the MI355X box's host (EPYC 9575F), T = N = 1000: sequential stage 1.5 ms, transforms 2.2 ms.
+    int nt = threads > 0 ? threads : 2;
+    if (nt > 16) nt = 16;
+    if (total < 200000) nt = 1;
+    const int W = nt - 1;                                       // transform workers
+    int slice_rows = (int)(16384 / (size_t)N);                  // ~8k pairs = 192 KB of attempts per slice
+    if (slice_rows < 1) slice_rows = 1;
+    const size_t cap = ((size_t)slice_rows * N) / 2 + 16;
+    constexpr int RING = 8;
+    std::vector<double> ring_mem;
+    try { ring_mem.resize((size_t)RING * 3 * cap); } catch (...) { return PFG_ERR_NOMEM; }
+    struct Slot { std::atomic<long> tag{0}; size_t q0 = 0, n = 0; };      // tag = slice + 1 while that slice waits in the buffer, 0 = free
+    Slot slots[RING];
+    std::atomic<long> n_slices{-1};                             // set when the main loop is done
+    auto seg = [&](long j, int which) -> double * { return ring_mem.data() + ((size_t)(j % RING) * 3 + which) * cap; };
+
+    auto transform_slice = [&](long j) {
+        const Slot &sl = slots[j % RING];
+        const double *a1 = seg(j, 0), *a2 = seg(j, 1), *a3 = seg(j, 2);
+        double tmp[1024];
+        size_t q = 0;
+        while (q < sl.n) {
+            const size_t m = sl.n - q < 512 ? sl.n - q : 512;
+            for (size_t i = 0; i < m; ++i) transform(a1[q + i], a2[q + i], a3[q + i], tmp[2 * i], tmp[2 * i + 1]);
+            // normals k0 .. k0 + 2m - 1 of the overall order: z0 first, then the rows of z
+            size_t k0 = 2 * (sl.q0 + q) + off, cnt = 2 * m;
+            const double *src = tmp;
+            if (k0 + cnt > total) { spill = tmp[cnt - 1]; spilled = true; --cnt; }      // only the very last pair
+            if (k0 < (size_t)N) {
+                const size_t h = (size_t)N - k0 < cnt ? (size_t)N - k0 : cnt;
+                std::memcpy(z0 + k0, src, h * sizeof(double));
+                k0 += h; src += h; cnt -= h;
+            }
+            if (cnt) stream_copy(avx2, z + (k0 - N), src, cnt);
+            q += m;
+        }
+    };
+    auto worker = [&](int w) {
+        for (long j = w;; j += W) {
+            Slot &sl = slots[j % RING];
+            unsigned spins = 0;
+            while (sl.tag.load(std::memory_order_acquire) != j + 1) {      // another slice may still sit in this buffer
+                const long ns = n_slices.load(std::memory_order_acquire);
+                if (ns >= 0 && j >= ns) return;
+                if (++spins < 64) _mm_pause(); else { std::this_thread::yield(); spins = 0; }
+            }
+            transform_slice(j);
+            sl.tag.store(0, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 0; w < W; ++w) pool.emplace_back(worker, w);
+
+    size_t npairs = 0;                       // accepted so far (all slices)
+    long j = 0;                              // current slice
+    size_t in_slice = 0;
+    double *p1 = seg(0, 0), *p2 = seg(0, 1), *p3 = seg(0, 2);
+    auto close_slice = [&]() {
+        Slot &sl = slots[j % RING];
+        sl.q0 = npairs - in_slice; sl.n = in_slice;
+        if (W > 0) sl.tag.store(j + 1, std::memory_order_release);
+        else transform_slice(j);
+        ++j;
+        in_slice = 0;
+        if (W > 0) {                         // the next buffer of the ring must have been drained
+            unsigned spins = 0;
+            while (slots[j % RING].tag.load(std::memory_order_acquire) != 0) {
+                if (++spins < 64) _mm_pause(); else { std::this_thread::yield(); spins = 0; }
+            }
+        }
+        p1 = seg(j, 0); p2 = seg(j, 1); p3 = seg(j, 2);
+    };
+    double ubuf[312];
     for (int row = 0; row <= T; ++row) {
         const size_t row_end = (size_t)N * (row + 1);
         if (row > 0) {                                // uniforms of timestep row - 1 come BEFORE its normals
@@ -133,14 +273,15 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
                 const int fit = (624 - mt.pos) / 2;       // whole doubles left in the current block
                 if (fit < 1) { ur[i++] = mt.next_double(); continue; }     // straddles a block boundary (or refill)
                 const int n = fit < N - i ? fit : N - i;
-                if (mt.avx2) doubles_avx2(mt.out + mt.pos, n, ur + i); else doubles_generic(mt.out + mt.pos, n, ur + i);
+                if (avx2) { doubles_avx2(mt.out + mt.pos, n, ubuf); stream_copy_avx2(ur + i, ubuf, (size_t)n); }
+                else doubles_generic(mt.out + mt.pos, n, ur + i);
                 mt.pos += 2 * n;
                 i += n;
             }
         }
         // attempts until this row's normals are covered (a pair started in this row may spill one
         // variate into the next row: the cache)
-        const size_t have = (lead_cached ? 1 : 0) + 2 * npairs;
+        const size_t have = off + 2 * npairs;
         size_t need_pairs = row_end > have ? (row_end - have + 1) / 2 : 0;
         while (need_pairs > 0) {
             const int avail = (624 - mt.pos) / 4;         // whole attempts left in the current block
@@ -148,56 +289,28 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
                 const double x1 = 2.0 * mt.next_double() - 1.0;
                 const double x2 = 2.0 * mt.next_double() - 1.0;
                 const double r2 = x1 * x1 + x2 * x2;
-                if (!(r2 >= 1.0 || r2 == 0.0)) { pairs[npairs++] = Pair{x1, x2, r2}; --need_pairs; }
+                if (!(r2 >= 1.0 || r2 == 0.0)) {
+                    p1[in_slice] = x1; p2[in_slice] = x2; p3[in_slice] = r2;
+                    ++in_slice; ++npairs; --need_pairs;
+                }
                 continue;
             }
             double cx1[156], cx2[156], cr2[156];
-            if (mt.avx2) candidates_avx2(mt.out + mt.pos, avail, cx1, cx2, cr2);
+            if (avx2) candidates_avx2(mt.out + mt.pos, avail, cx1, cx2, cr2);
             else candidates_generic(mt.out + mt.pos, avail, cx1, cx2, cr2);
-            int used = 0;
-            size_t got = 0;
-            while (used < avail && got < need_pairs) {    // in order, stop at the last attempt this row consumes
-                const double r2 = cr2[used];
-                pairs[npairs + got] = Pair{cx1[used], cx2[used], r2};      // branch-free: a rejected attempt is overwritten
-                got += (r2 >= 1.0 || r2 == 0.0) ? 0 : 1;
-                ++used;
-            }
+            size_t got = 0;          // in order, stopping at the last attempt this row consumes
+            const int used = avx2 ? accept_avx2(cx1, cx2, cr2, avail, need_pairs, p1 + in_slice, p2 + in_slice, p3 + in_slice, got)
+                                  : accept_generic(cx1, cx2, cr2, avail, need_pairs, p1 + in_slice, p2 + in_slice, p3 + in_slice, got);
+            in_slice += got;
             npairs += got;
             need_pairs -= got;
             mt.pos += 4 * used;
         }
+        if ((row + 1) % slice_rows == 0 || row == T) close_slice();
     }
-    // transforms: independent per pair -> worker threads
-    const size_t off = lead_cached ? 1 : 0;
-    double spill = 0.0;
-    bool spilled = false;
-    auto work = [&](size_t q0, size_t q1) {
-        for (size_t q = q0; q < q1; ++q) {
-            double a, b;
-            transform(pairs[q], a, b);
-            const size_t ka = 2 * q + off, kb = ka + 1;
-            *dst(ka) = a;
-            if (kb < total) *dst(kb) = b;
-            else { spill = b; spilled = true; }       // only the last pair can spill (one writer)
-        }
-    };
-    // measured on the MI355X box's host (T = N = 1000): 4.4 / 3.5 / 4.0 / 3.8 ms with 1 / 2 / 4 / 8 threads
-    // (the sequential word + accept stage dominates; NumPy's own calls: 13.6 ms)
-    int nt = threads > 0 ? threads : 2;
-    if (nt > 16) nt = 16;
-    if (npairs < 100000) nt = 1;
-    if (nt == 1) {
-        work(0, npairs);
-    } else {
-        std::vector<std::thread> pool;
-        const size_t chunk = (npairs + nt - 1) / nt;
-        for (int w = 0; w < nt; ++w) {
-            const size_t a = (size_t)w * chunk, b = a + chunk < npairs ? a + chunk : npairs;
-            if (a < b) pool.emplace_back(work, a, b);
-        }
-        for (auto &th : pool) th.join();
-    }
-    (void)k;
+    n_slices.store(j, std::memory_order_release);
+    for (auto &th : pool) th.join();
+    if (avx2) _mm_sfence();                                   // non-temporal stores visible before the buffers are handed on
     *pos = mt.pos;
     *has_gauss = spilled ? 1 : 0;
     *gauss = spilled ? spill : 0.0;

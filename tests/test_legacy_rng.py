@@ -36,7 +36,7 @@ def test_native_streams_bit_identical(N, T, seed, pre, threads):
 
 @pytest.mark.parametrize("N,T,seed,pre,threads", [
     (1000, 1000, 21, 0, 0), (999, 130, 22, 1, 2), (64, 2000, 23, 3, 0), (17, 7001, 24, 0, 4), (100000, 1, 25, 1, 0),
-    (1250, 81, 26, 2, 16)])
+    (1250, 81, 26, 2, 16), (1000, 400, 27, 1, 3), (2500, 100, 28, 0, 4), (999, 333, 29, 3, 8), (30, 9000, 30, 1, 16)])
 def test_pipelined_generator_bit_identical(N, T, seed, pre, threads):
     """Streams long enough for the pipelined path (recurrence on a producer thread, transforms on workers):
     same numbers, same final state, also over two calls in a row."""

@@ -13,7 +13,7 @@ int main() {
     const int B = 7300;
     const bool avx2 = __builtin_cpu_supports("avx2");
     static double x1[156], x2[156], r2[156], d[312];
-    std::vector<Pair> pairs(600000);
+    std::vector<double> q1(600016), q2(600016), q3(600016);
     for (int rep = 0; rep < 3; ++rep) {
         double t0 = now();
         for (int b = 0; b < B; ++b) { if (avx2) mt_block_avx2(key); else mt_block_generic(key); }
@@ -28,13 +28,14 @@ int main() {
         for (int b = 0; b < B / 2; ++b) {
             candidates_avx2(out, 156, x1, x2, r2);
             size_t got = 0;
-            for (int i = 0; i < 156; ++i) { pairs[np + got] = Pair{x1[i], x2[i], r2[i]}; got += (r2[i] >= 1.0 || r2[i] == 0.0) ? 0 : 1; }
+            if (avx2) accept_avx2(x1, x2, r2, 156, 1000, q1.data() + np, q2.data() + np, q3.data() + np, got);
+            else accept_generic(x1, x2, r2, 156, 1000, q1.data() + np, q2.data() + np, q3.data() + np, got);
             np = (np + got) % 500000;
             out[b % 624] += (uint32_t)np;
         }
         double t5 = now();
         double acc = 0;
-        for (size_t q = 0; q < 500000; ++q) { double a, bb; Pair p{0.3, 0.4, 0.25 + 1e-7 * (q % 1000)}; transform(p, a, bb); acc += a; }
+        for (size_t q = 0; q < 500000; ++q) { double a, bb; transform(0.3, 0.4, 0.25 + 1e-7 * (q % 1000), a, bb); acc += a; }
         double t6 = now();
         std::printf("avx2 %d | recurrence %.2f ms | temper %.2f | doubles(all blocks) %.2f | candidates(all blocks) %.2f | candidates+accept(half) %.2f | 5e5 transforms %.2f  (%g)\n",
                     (int)avx2, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, (t6 - t5) * 1e3, acc);
