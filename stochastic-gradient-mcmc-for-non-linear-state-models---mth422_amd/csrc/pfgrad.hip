@@ -3,6 +3,7 @@
 // kernel, compiled in parallel by sgmcmc_ssm_amd/_build.py); this unit holds the dispatcher, the
 // small update / window / KSD kernels and the extern "C" entry points.
 #include <mutex>
+#include <unordered_map>
 #include "pfg_host.hpp"
 #include "pfg_device.hpp"
 #include "pfg_elementwise.hpp"
@@ -701,6 +702,17 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         oi += n;
         return d;
     };
+    // observations / window weights that many windows of the batch share (same host pointer and length) are
+    // staged once: 12288 chains on one series would otherwise carry 98 MB of copies of the same 8 KB
+    std::unordered_map<const double *, std::pair<size_t, const double *>> shared;
+    auto put_shared = [&](const double *src, size_t n) -> const double * {
+        if (!src || n == 0) return nullptr;
+        auto it = shared.find(src);
+        if (it != shared.end() && it->second.first == n) return it->second.second;
+        const double *d = put(src, n);
+        shared[src] = std::make_pair(n, d);
+        return d;
+    };
     auto take = [&](bool want, size_t n) -> double * {
         if (!want) return nullptr;
         double *d = dout + oo;
@@ -719,8 +731,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         pfg_dev_problem &d = ctx->h_desc[b];
         const int tL = q.tL < q.T ? q.tL : q.T;
         const int nw = q.weights ? tL - q.t1 : 0;
-        d.y = put(q.y, q.T);
-        d.weights = put(q.weights, nw > 0 ? nw : 0);
+        d.y = put_shared(q.y, q.T);
+        d.weights = put_shared(q.weights, nw > 0 ? nw : 0);
         {
             double th[PFG_MAX_THETA] = {0, 0, 0, 0};
             for (int j = 0; j < P; ++j) th[j] = q.theta[j];
