@@ -21,6 +21,17 @@ __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (
 // Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
 __host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 512 || NT == 1024; }
 
+// workgroup barrier; a one-wave workgroup only needs its own LDS accesses kept in program order (the LDS
+// executes a wave's instructions in order): no s_barrier, no drain of the LDS queue
+template <int NW> __device__ __forceinline__ void block_sync() {
+    if (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
 template <int NT, int PPT> struct RegLayout {
     static constexpr int NW = NT / WAVE;
     static constexpr int RED = PPT * NW + NW + PFG_MAX_STAT * NW + 8;  // doubles of scratch
@@ -277,12 +288,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
         for (int k = 1; k < PPT; ++k) ml = fmaxf(ml, (float)lw[k]);
         ml = wave_max(ml);
-        if (lane == 0) red_maxf[wave] = ml;
+        if (NW > 1 && lane == 0) red_maxf[wave] = ml;
         PFG_PH(0)
-        __syncthreads();                                                        // barrier 1
+        block_sync<NW>();                                                       // barrier 1
         PFG_PH(1)
         {
-            float mm = red_maxf[0];
+            float mm = NW > 1 ? red_maxf[0] : ml;     // one wave: its maximum IS the block maximum, no LDS round trip
 #pragma unroll
             for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red_maxf[w]);
             m = uniform_f64((double)mm);      // f32-rounded max: a valid shift for log_normalize (see wave_max)
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 if (lane == 0) red_S[h * NW + wave] = part;
             }
         }
+        double wave_inc = 0.0;          // BLK: this wave's inclusive scan (lane 63 = the wave total)
         if (BLK) {
 #pragma unroll
             for (int k = 1; k < PPT; ++k) cs[k] += cs[k - 1];
@@ -309,7 +321,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             const double exc = inc - cs[PPT - 1];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) cs[k] += exc;
-            if (lane == WAVE - 1) red_scan[wave] = inc;
+            if (NW > 1 && lane == WAVE - 1) red_scan[wave] = inc;
+            wave_inc = inc;
         } else {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -330,9 +343,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             }
         }
         PFG_PH(2)
-        __syncthreads();                                                        // barrier 2
+        block_sync<NW>();                                                       // barrier 2
         PFG_PH(3)
-        if (BLK) {
+        if (BLK && NW == 1) {
+            // one wave: no other totals to add, W is the scan's last lane
+            W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wave_inc), WAVE - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(wave_inc), WAVE - 1));
+        } else if (BLK) {
             // NW wave totals: exclusive prefix by a DPP scan over the first lanes
             const double tot = (lane < NW) ? red_scan[lane] : 0.0;
             double inc = tot;
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 }
         }
         PFG_PH(4)
-        __syncthreads();                                                        // barrier 3
+        block_sync<NW>();                                                       // barrier 3
         PFG_PH(5)
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
@@ -542,7 +559,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
             }
             PFG_PH(7)
-            if (!PP) __syncthreads();                                           // barrier 4 (single buffer)
+            if (!PP) block_sync<NW>();                                          // barrier 4 (single buffer)
             PFG_PH(8)
             if (RNG != PFG_RNG_REPLAY) {
                 draw_normals(zz);
