@@ -260,6 +260,14 @@ __device__ __forceinline__ double sqrt_pos(double x) {
     return fma(d, h, g);
 }
 
+// 1/x for finite x > 0 (no special cases): v_rcp_f64 + two Newton steps (< 1 ulp) instead of the IEEE division
+// sequence (div_scale x2, rcp, five fma, div_fmas, div_fixup)
+__device__ __forceinline__ double rcp_pos(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 template <typename REAL, bool TAB> struct Math;
 template <> struct Math<double, true> {
     TabF64 t;
@@ -271,6 +279,9 @@ template <> struct Math<double, true> {
 #endif
     __device__ __forceinline__ double log(double x) const { return log_tab(x, t.lg); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    // finite positive arguments only (device-generator units): no special-case handling
+    __device__ __forceinline__ double sqrt_pos(double x) const { return pfg::sqrt_pos(x); }
+    __device__ __forceinline__ double rcp_pos(double x) const { return pfg::rcp_pos(x); }
     // two independent standard normals from two words (Box-Muller, both branches).  The draws
     // are INPUTS of the filter, like the 32-bit uniforms: they are generated with the f32
     // transcendental units (v_log / v_sin / v_cos: ~12 issue slots per normal instead of ~25 for
@@ -298,6 +309,8 @@ template <> struct Math<double, false> {
     __device__ __forceinline__ double exp_finite(double x) const { return ::exp(x); }
     __device__ __forceinline__ double log(double x) const { return ::log(x); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
+    __device__ __forceinline__ double sqrt_pos(double x) const { return ::sqrt(x); }
+    __device__ __forceinline__ double rcp_pos(double x) const { return 1.0 / x; }
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double &z0, double &z1) const {
         const double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
         const double r = ::sqrt(-2.0 * ::log(u1));
@@ -317,6 +330,8 @@ template <bool TAB> struct Math<float, TAB> {
     __device__ __forceinline__ float exp_finite(float x) const { return __expf(x); }
     __device__ __forceinline__ float log(float x) const { return __logf(x); }
     __device__ __forceinline__ float sqrt(float x) const { return sqrtf(x); }
+    __device__ __forceinline__ float sqrt_pos(float x) const { return sqrtf(x); }
+    __device__ __forceinline__ float rcp_pos(float x) const { return 1.0f / x; }
     __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, float &z0, float &z1) const {
         const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1), 24 bits
         const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1): angle / 2pi

@@ -159,18 +159,23 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
         REAL s2 = (c.alpha + c.beta * xx) + c.gamma * xp[1];
         REAL x1;
         if (KERNEL == PFG_KERNEL_PRIOR) {
+#ifdef PFG_FAST_ALGEBRA
+            x1 = mth.sqrt_pos(s2) * z;
+#else
             x1 = mth.sqrt(s2) * z;
+#endif
             REAL diff = y - x1;
             lw = (c.c0 + (-half * (diff * diff)) * c.Rinv) + c.logLRinv;
         } else {
 #ifdef PFG_FAST_ALGEBRA
-            // device-generator units: 1/s2 is shared with the score below, the step's uniform
-            // factors are collected (3 divisions per particle instead of 4)
-            const REAL rs2 = (REAL)1 / s2;
-            REAL var = (REAL)1 / (c.Rinv + rs2);
-            x1 = fma(mth.sqrt(var), z, var * (y * c.Rinv));
-            REAL v2 = s2 + c.R;
-            lw = fma(-half * (y * y), (REAL)1 / v2, c.c0) + (-half * mth.log(v2));
+            // device-generator units: 1/(Rinv + 1/s2) = s2 R / (s2 + R), so the proposal variance shares its
+            // reciprocal with the weight; s2 > 0 and s2 + R > 0 are finite: rcp + Newton, rsq + Newton
+            // (two reciprocals and no IEEE division per particle instead of four divisions)
+            const REAL v2 = s2 + c.R;
+            const REAL rv2 = mth.rcp_pos(v2);
+            const REAL var = (s2 * c.R) * rv2;
+            x1 = fma(mth.sqrt_pos(var), z, var * (y * c.Rinv));
+            lw = fma(-half * (y * y), rv2, c.c0) + (-half * mth.log(v2));
 #else
             REAL var = (REAL)1 / (c.Rinv + (REAL)1 / s2);
             REAL mean = var * (y * c.Rinv);
@@ -184,7 +189,7 @@ __device__ __forceinline__ void particle_step(const Consts<REAL> &c, const MATH 
             // garch/helper.py:350-370, order [LRinv, log_mu, logit_phi, logit_lambduh]
             REAL v = s2;
 #ifdef PFG_FAST_ALGEBRA
-            const REAL rv = (KERNEL == PFG_KERNEL_PRIOR) ? (REAL)1 / v : (REAL)1 / v;   // CSE'd with rs2 above
+            const REAL rv = mth.rcp_pos(v);
             const REAL gv = (-half * (v - x1 * x1)) * (rv * rv);
             const REAL omp = (REAL)1 - c.phi, oml_ = (REAL)1 - c.lam;
             add[1] = gv * (omp * c.mu);
