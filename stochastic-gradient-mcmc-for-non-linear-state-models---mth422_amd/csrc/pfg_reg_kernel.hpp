@@ -86,7 +86,10 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // fp64 latencies better than the same independent work inside one wave; the particle arrays on a 512-byte
 // boundary so that their base folds into the ds_read2st64 / ds_write2st64 offsets (0 %); descriptor-field tests
 // hoisted out of the loop and the observations held 64 steps at a time in the lanes of a register instead of a
-// scalar load per step (+0.5 % / +2 %: 15 more spilled registers).
+// scalar load per step (+0.5 % / +2 %: 15 more spilled registers); the CDF as an implicit 4-ary search tree (a node
+// = three pivots read with ds_read2_b32 + ds_read_b32, five dependent LDS round trips instead of ten, no padding to
+// undo; bit-identical ancestors): SVM +6 %, GARCH +3 %, N = 100 0 %, N = 4000 -2 % -- three compares and two selects per
+// level cost more than the round trips they save.
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
