@@ -518,15 +518,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         } else if (FAST) {
             // sentinel-padded cdf, physical positions: log2(NT*PPT) fixed probes whose offsets
             // fold into the ds_read immediates; logical index recovered once at the end
+            // on byte offsets, like the 32-bit search above (the LDS address is the search variable)
+            using lds_f64 = const __attribute__((address_space(3))) double;
+            const uint32_t cdf_base = (uint32_t)(uintptr_t)(lds_f64 *)cdf;
+            uint32_t off[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) off[k] = cdf_base;
 #pragma unroll
             for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
                 const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
                 const int adv = step + (step >> 5);
+                double cv[PPT];
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) anc[k] += (cdf[anc[k] + probe] <= uu[k]) ? adv : 0;
+                for (int k = 0; k < PPT; ++k) cv[k] = *(lds_f64 *)(uintptr_t)(off[k] + 8u * probe);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) off[k] += (cv[k] <= uu[k]) ? 8u * adv : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) anc[k] -= (anc[k] * 993) >> 15;      // p - p/33 (exact for p < 32768)
+            for (int k = 0; k < PPT; ++k) {
+                const uint32_t p = (off[k] - cdf_base) >> 3;
+                anc[k] = (int)(p - (__umul24(p, 993u) >> 15));                  // p - p/33 (exact for p < 32768)
+            }
         } else {
             for (int step = np2 >> 1; step >= 1; step >>= 1) {
 #pragma unroll
