@@ -357,8 +357,10 @@ def cpu_rehearsal(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: ~6.5 s of timed GPU work on the headline config (54 ms per step), long enough for a 5-s utilisation
+    # sampler beside the run to see it; the whole default run still ends within a minute
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="0 = the config's default")
     ap.add_argument("--model", default=None, choices=["svm", "garch"], help="(compat) svm = c2, garch = c3")
