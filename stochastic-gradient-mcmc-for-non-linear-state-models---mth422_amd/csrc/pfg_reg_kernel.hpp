@@ -89,7 +89,9 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // scalar load per step (+0.5 % / +2 %: 15 more spilled registers); the CDF as an implicit 4-ary search tree (a node
 // = three pivots read with ds_read2_b32 + ds_read_b32, five dependent LDS round trips instead of ten, no padding to
 // undo; bit-identical ancestors): SVM +6 %, GARCH +3 %, N = 100 0 %, N = 4000 -2 % -- three compares and two selects per
-// level cost more than the round trips they save.
+// level cost more than the round trips they save; the children of a step kept in registers and written behind
+// barrier 1 of the NEXT step (every wave is past its gathers by then: three barriers per timestep on one buffer, the
+// gathers' latency overlapped with the generator calls): SVM +5.5 % (32 spilled registers), GARCH +1 %, N = 4000 +2 %.
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
