@@ -400,6 +400,9 @@ def main():
     if world_env > ndev and not args.rehearsal:
         raise SystemExit("--gpus {0} but only {1} GPU(s) visible: ranks would share devices "
                          "(pass --rehearsal to fold them; the line is then labelled)".format(world_env, ndev))
+    if world_env > ndev:
+        # ranks folded onto fewer devices (--rehearsal): RCCL refuses two ranks on one GPU, the rendezvous runs on gloo
+        os.environ.setdefault("PFG_DIST_BACKEND", "gloo")
     rank, world, local_rank = distributed.init_from_env()
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)

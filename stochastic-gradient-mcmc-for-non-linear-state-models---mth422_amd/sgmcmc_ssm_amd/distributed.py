@@ -23,10 +23,17 @@ def init_from_env(backend=None):
             backend = os.environ.get("PFG_DIST_BACKEND")     # rehearsal override (e.g. gloo on one GPU)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+            index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(index)
+            # bind the communicator to this rank's GPU: barrier() otherwise guesses the device from the global rank
+            kwargs["device_id"] = torch.device("cuda", index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        except TypeError:                       # a torch without the device_id argument
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
