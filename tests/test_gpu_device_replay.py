@@ -79,7 +79,7 @@ CASES = [
     ("garch", "optimal", "nemeth", 0.9, 1024, 40, None, "wg512x2s", (512, 2, "fixed32")),
     ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
     # config 4: SVM N=4000, LDS-resident 1024 x 4
-    ("svm", "prior", "poyiadjis_N", 1.0, 4000, 250, None, "wg1024x4s", (1024, 4, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 4000, 1000, None, "wg1024x4s", (1024, 4, "fixed32")),   # full size
     # config 5: SVM N=10000, S=16 B=4 window, large-N kernel (fp64 CDF)
     ("svm", "prior", "poyiadjis_N", 1.0, 10000, 24, (4, 20, True), "big16384", (16384, 1, "f64_uniform")),
     ("svm", "prior", "poyiadjis_N", 1.0, 9001, 30, None, "big16384", (16384, 1, "f64_uniform")),
