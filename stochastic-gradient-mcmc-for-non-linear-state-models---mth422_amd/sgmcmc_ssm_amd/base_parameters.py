@@ -12,9 +12,22 @@ because the SGLD noise is drawn per variable in that order (sgmcmc_sampler.py:54
 Host-side only: O(#parameters) work per SGLD step.
 """
 from copy import deepcopy
+import functools
 import logging
 
 import numpy as np
+
+
+@functools.lru_cache(maxsize=None)
+def _tril(n):
+    """np.tril_indices(n), computed once per size (it showed up as a quarter of a short-window SGLD step)."""
+    return np.tril_indices(int(n))
+
+
+@functools.lru_cache(maxsize=None)
+def _triu1(n):
+    return np.triu_indices(int(n), 1)
+
 import scipy.stats
 from scipy.special import expit, logit
 
@@ -85,7 +98,7 @@ class MatrixVar(object):
 def _tril_to_mat(vec):
     n = int(np.sqrt(len(vec) * 2))
     mat = np.zeros((n, n), dtype=float)
-    mat[np.tril_indices(n)] = vec
+    mat[_tril(n)] = vec
     return mat
 
 
@@ -109,13 +122,13 @@ class CholPrecisionVar(object):
             L = np.array(kwargs[self.chol]).astype(float)
             if L.ndim != 2 or L.shape[0] != L.shape[1]:
                 raise ValueError("{} must be square matrix".format(self.chol))
-            n, vec = L.shape[0], L[np.tril_indices_from(L)]
+            n, vec = L.shape[0], L[_tril(L.shape[0])]
         elif self.name in kwargs:
             X = np.array(kwargs[self.name]).astype(float)
             if X.ndim != 2 or X.shape[0] != X.shape[1]:
                 raise ValueError("{} must be square matrix".format(self.name))
             L = np.linalg.cholesky(np.linalg.inv(X))
-            n, vec = X.shape[0], L[np.tril_indices_from(L)]
+            n, vec = X.shape[0], L[_tril(L.shape[0])]
         else:
             raise ValueError("{} not provided".format(self.chol))
         params.var_dict[self.vec] = vec
@@ -135,7 +148,7 @@ class CholPrecisionVar(object):
         if opts.get('thresh', True):
             # reflect a negative Cholesky diagonal: chol(L L' + 1e-16 I), covariance.py:68-80
             L = getattr(params, self.chol)
-            L[np.triu_indices_from(L, 1)] = 0
+            L[_triu1(L.shape[0])] = 0
             if np.any(np.diag(L) < 0.0):
                 logger.info("Reflecting {0}: {1} < 0.0".format(self.chol, L))
                 L[:] = np.linalg.cholesky(np.dot(L, L.T) + np.eye(L.shape[0]) * 1e-16)
@@ -145,7 +158,7 @@ class CholPrecisionVar(object):
         vec, chol, prec = self.vec, self.chol, self.prec
 
         def set_chol(self_, value):
-            self_.var_dict[vec] = value[np.tril_indices_from(value)]
+            self_.var_dict[vec] = value[_tril(value.shape[0])]
 
         def get_prec(self_):
             L = _tril_to_mat(self_.var_dict[vec])
@@ -322,7 +335,7 @@ class WishartPrecisionPrior(object):
         draw = scipy.stats.wishart(df=df, scale=scale).rvs()
         P = np.array([[draw]]) if np.size(scale) == 1 else draw
         L = np.linalg.cholesky(P)
-        var_dict[self.vec] = L[np.tril_indices_from(L)]
+        var_dict[self.vec] = L[_tril(L.shape[0])]
 
     def logprior(self, prior, parameters):
         return scipy.stats.wishart.logpdf(getattr(parameters, self.prec),
@@ -332,7 +345,7 @@ class WishartPrecisionPrior(object):
         scale, df = prior.hyperparams[self.scale], prior.hyperparams[self.df]
         L = getattr(parameters, self.chol)
         g = (df - L.shape[0] - 1) * np.linalg.inv(L.T) - np.linalg.solve(scale, L)
-        grad[self.vec] = g[np.tril_indices_from(g)]
+        grad[self.vec] = g[_tril(g.shape[0])]
 
     def default_kwargs(self, out, var, **dims):
         n = dims[self.dim]
@@ -541,14 +554,14 @@ class CholPrecisionPrecond(object):
     def precondition(self, out, grad, parameters):
         Qinv = getattr(parameters, self.inv)
         G = np.zeros(Qinv.shape)
-        G[np.tril_indices_from(G)] = grad[self.vec]
+        G[_tril(G.shape[0])] = grad[self.vec]
         P = np.dot(0.5 * Qinv, G)
-        out[self.vec] = P[np.tril_indices_from(P)]
+        out[self.vec] = P[_tril(P.shape[0])]
 
     def noise(self, out, parameters):
         L = _tril_to_mat(getattr(parameters, self.vec))
         Z = np.dot(np.sqrt(0.5) * L, np.random.normal(loc=0, size=L.shape))
-        out[self.vec] = Z[np.tril_indices_from(Z)]
+        out[self.vec] = Z[_tril(Z.shape[0])]
 
     def correction(self, out, parameters):
         vec = getattr(parameters, self.vec)
