@@ -26,7 +26,14 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 def _contract(src):
     """REPLAY kernels keep the reference's NumPy operation order (no fused multiply-add unless
     written as fma()); the device-generator kernels have no such parity to keep and fuse."""
-    return ["-ffp-contract=fast", "-DPFG_FAST_ALGEBRA=1"] + os.environ.get("PFG_EXTRA_DEVICE_FLAGS", "").split() if src.endswith("_device.hip") else ["-ffp-contract=off"]
+    if not src.endswith("_device.hip"):
+        return ["-ffp-contract=off"]
+    flags = ["-ffp-contract=fast", "-DPFG_FAST_ALGEBRA=1"] + os.environ.get("PFG_EXTRA_DEVICE_FLAGS", "").split()
+    if "_lgssm_" in os.path.basename(src) and not os.environ.get("PFG_EXTRA_DEVICE_FLAGS"):
+        # measured per unit (A/B builds): the max-ILP scheduling strategy is worth 6.7 % on BASELINE config 1 (LGSSM,
+        # one wave per window: 2.35 -> 2.20 ms per 16384 chains); SVM +1 %, GARCH +2 % slower with it, so only here
+        flags += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    return flags
 
 
 def _hipcc():
