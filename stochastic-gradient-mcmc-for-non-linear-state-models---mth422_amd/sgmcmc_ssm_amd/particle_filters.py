@@ -159,6 +159,9 @@ class _Speculation(object):
 
 
 speculation = _Speculation()
+# a prefetch still writing into its buffers must not outlive the interpreter's teardown of those buffers
+import atexit
+atexit.register(speculation.cancel)
 
 
 def draw_replay_streams(N, T, random_state=None, buffers=None):
