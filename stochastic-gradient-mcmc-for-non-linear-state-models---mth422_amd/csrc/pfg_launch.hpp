@@ -39,6 +39,9 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
         case 4:
             if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st);
             break;
+        case 7:
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, true>(ctx, n_max, B, dp, st);
+            break;
         case 6:
             if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_GARCH && sizeof(REAL) == 8)
                 return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, false>(ctx, n_max, B, dp, st);

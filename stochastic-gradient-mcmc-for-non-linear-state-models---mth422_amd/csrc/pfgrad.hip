@@ -45,8 +45,10 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               {64, 2, true, "wg64x2"},
                               // GARCH fp64: six LDS arrays allow two workgroups per CU; eight waves each
                               // put four waves on a SIMD (256x4: two)
-                              {512, 2, false, "wg512x2s"} };
-constexpr int kLds4096Variant = 4, kTinyVariant = 5, kGarchVariant = 6;
+                              {512, 2, false, "wg512x2s"},
+                              // 128 < N <= 256, many windows: still one wave per window, four particles per lane
+                              {64, 4, true, "wg64x4"} };
+constexpr int kLds4096Variant = 4, kTinyVariant = 5, kGarchVariant = 6, kTiny4Variant = 7;
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -86,6 +88,9 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
     if (n_max <= 128 && batch > kLatencyBatch &&
         lds_bytes(model, dtype, rng, kVariants[kTinyVariant], n_max) <= kLdsLimit)
         return kTinyVariant;
+    if (n_max > 128 && n_max <= 256 && batch > kLatencyBatch && rng == PFG_RNG_DEVICE &&
+        lds_bytes(model, dtype, rng, kVariants[kTiny4Variant], n_max) <= kLdsLimit)
+        return kTiny4Variant;
     if (batch <= kLatencyBatch && n_max > 256 && n_max <= 1024 &&
         lds_bytes(model, dtype, rng, kVariants[kLatencyVariant], n_max) <= kLdsLimit)
         return kLatencyVariant;

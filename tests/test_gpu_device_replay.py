@@ -73,6 +73,9 @@ CASES = [
     # config 1: LGSSM T=200 N=100 (one wave per window)
     ("lgssm", "optimal", "poyiadjis_N", 1.0, 100, 200, None, "wg64x2", (64, 2, "fixed32")),
     ("lgssm", "prior", "nemeth", 0.9, 128, 50, None, "wg64x2", (64, 2, "fixed32")),
+    # 128 < N <= 256 in batches: one wave per window, four particles per lane
+    ("lgssm", "optimal", "poyiadjis_N", 1.0, 200, 80, None, "wg64x4", (64, 4, "fixed32")),
+    ("svm", "prior", "nemeth", 0.95, 256, 40, (5, 30, True), "wg64x4", (64, 4, "fixed32")),
     # config 3: GARCH N=1000, S=16 B=4 window
     ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg512x2s", (512, 2, "fixed32")),
     ("garch", "prior", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg512x2s", (512, 2, "fixed32")),
