@@ -542,6 +542,9 @@ def main():
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
             if single:
                 line["single_chain_speedup_vs_cpu_1core"] = single / line["cpu_baseline"]["value"]
+            if line["cpu_baseline"].get("all_cores_bound"):
+                # the like-for-like node comparison: every host core running its own chain vs every CU doing so
+                line["speedup_vs_cpu_all_cores_bound"] = line["value"] / line["cpu_baseline"]["all_cores_bound"]
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
