@@ -29,9 +29,11 @@ def test_registered_streams_same_result(golden_sampler):
         assert np.array_equal(a["mean_stat"], o["mean_stat"]) and a["loglik"] == o["loglik"]
 
 
-def test_pooled_stream_buffers_are_registered_and_reused():
+def test_pooled_stream_buffers_are_registered_and_reused(monkeypatch):
     from sgmcmc_ssm_amd import particle_filters as pfm
     N, T = 1000, 200                       # 1.6 MB per array: above the pinning threshold
+    monkeypatch.setattr(pfm, "_PIN_MAX_BYTES", pfm._pinned_bytes + (64 << 20))     # headroom whatever ran before
+    pfm._stream_pool.pop((N, T), None)     # ... and a fresh pair, not one an earlier test left in the pool
     n0 = len(pfm._pinned)
     bufs = pfm._stream_buffers(N, T)
     assert len(pfm._pinned) == n0 + 1 and pfm._is_pinned(bufs)
