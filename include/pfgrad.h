@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 111          /* 0.1.11 */
+#define PFG_VERSION 120          /* 0.1.20 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -123,6 +123,10 @@ typedef struct pfg_problem {
      * statistic matrix through HBM step by step.  NEMETH (any lambduh) and PARIS. */
     int32_t elementwise;
     const double *pred_z;
+    /* DEVICE rng: SGLD step the window belongs to, mixed into the generator key exactly as a resident chain's
+     * device-side counter (*pfg_dev_problem.step_ctr) is: a window run through pfg_run_batch with
+     * (seed, stream = global chain id, step) draws what that chain draws at that step through pfg_launch_device. */
+    uint64_t step;
 } pfg_problem;
 
 /* Result of one window; optional arrays are caller-allocated HOST buffers or NULL. */

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pfgrad.h"
@@ -59,8 +60,12 @@ struct pfg_ctx {
     std::string err;
     pfg_host::Arena in, out, desc, scratch, work;      // work: device-only buffers (elementwise-statistics pass)
     pfg_host::HostArena h_in, h_out;
+    std::vector<double> h_in_pageable;   // staging when the pinned arena cannot be had (hipHostMalloc refused)
     std::vector<pfg_dev_problem> h_desc;
     const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched
+    // largest dynamic-LDS size hipFuncAttributeMaxDynamicSharedMemorySize has been set to, per kernel: the
+    // attribute is per (function, device) and a context is bound to one device
+    std::unordered_map<const void *, size_t> lds_set;
 };
 
 namespace pfg_host {

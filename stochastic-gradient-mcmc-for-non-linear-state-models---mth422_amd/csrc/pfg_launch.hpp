@@ -7,14 +7,17 @@
 namespace pfg_host {
 
 // Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize; set it once per kernel and
-// process (again only if a larger size is asked for), not on every launch.  One process drives one GPU.
+// CONTEXT (again only if a larger size is asked for), not on every launch.  The attribute belongs to the
+// (function, device) pair and a context is bound to one device; a context is used by one thread at a time.
 #define PFG_ENSURE_LDS(ctx, kern, lds)                                                                    \
     do {                                                                                                  \
-        static size_t pfg_lds_set_ = 0;                                                                   \
-        if ((lds) > 64 * 1024 && (lds) > pfg_lds_set_) {                                                  \
-            PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)));   \
-            pfg_lds_set_ = (lds);                                                                         \
+        if ((lds) > 64 * 1024) {                                                                          \
+            size_t &pfg_lds_set_ = (ctx)->lds_set[reinterpret_cast<const void *>(kern)];                  \
+            if ((lds) > pfg_lds_set_) {                                                                   \
+                PFG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                    \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds))); \
+                pfg_lds_set_ = (lds);                                                                     \
+            }                                                                                             \
         }                                                                                                 \
     } while (0)
 
@@ -45,6 +48,23 @@ int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, h
         case 6:
             if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_GARCH && sizeof(REAL) == 8)
                 return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, false>(ctx, n_max, B, dp, st);
+            break;
+        // one wave per window on ONE state buffer (a wave's LDS accesses execute in order: the gather of a step is
+        // over before its stores are issued, the fourth "barrier" is free) -- half the LDS per window
+        case 10:
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, false>(ctx, n_max, B, dp, st);
+            break;
+        case 11:
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, false>(ctx, n_max, B, dp, st);
+            break;
+        // 1024 < N <= 4096, SVM fp64: the same 4096 LDS slots in 512 / 256 threads (no 128-VGPR cap)
+        case 8:
+            if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_SVM && sizeof(REAL) == 8)
+                return launch_one<MODEL, KERNEL, REAL, 512, 8, RNG, false>(ctx, n_max, B, dp, st);
+            break;
+        case 9:
+            if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_SVM && sizeof(REAL) == 8)
+                return launch_one<MODEL, KERNEL, REAL, 256, 16, RNG, false>(ctx, n_max, B, dp, st);
             break;
     }
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");

@@ -58,10 +58,21 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
 // waves per SIMD the register allocator should aim for: what LDS lets a CU hold anyway.
 // 256x4 fp64: ping-pong state is 80 KB/workgroup -> 2 workgroups (2 waves/SIMD); the single
 // buffer is 50 KB -> 3, which is worth a few spilled registers (measured +15 %).
+// One-wave workgroups (NT = 64): LDS admits many windows per CU, the register budget decides how many waves a SIMD
+// holds (-DPFG_OCC64=n for A/B builds)
+#ifndef PFG_OCC64
+#define PFG_OCC64 4
+#endif
+// 4096 particle slots in fewer than 1024 threads (N <= 4096 state fills the LDS of a CU: ONE workgroup per CU
+// whatever its thread count): 512 threads = 2 waves per SIMD and 256 VGPRs, 256 threads = 1 wave per SIMD and 512
+__host__ __device__ constexpr bool occ_lds4096(int NT, int PPT) { return NT * PPT == 4096 && NT < 1024; }
 __host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
-    return (NT >= 512 || NT == 64 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
+    if (occ_lds4096(NT, PPT)) return NT == 512 ? 2 : 1;
+    if (NT == 64) return PFG_OCC64;
+    return (NT >= 512 || PPT == 1 || dev4) ? 4 : ((PP && real == 8) ? 2 : 3);
 }
 __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
+    if (occ_lds4096(NT, PPT)) return NT == 512 ? 2 : 1;
     if (NT == 512) return 4;        // two 8-wave workgroups per CU
     return dev4 ? 4 : ((NT == 256 && PPT == 4 && !PP) ? 3 : 1);
 }
@@ -154,7 +165,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     // order a thread's PPT weights are contiguous: one in-register prefix + ONE wave scan per
     // thread instead of PPT wave scans.  REPLAY keeps the reference's index order (parity).
     constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
-    constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : 3));
+    constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : (PPT == 8 ? 3 : 4)));
+    static_assert(PPT <= 16, "LOG_PPT covers 1, 2, 4, 8, 16 particles per thread");
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
     // binary search probes at power-of-two strides, which would otherwise all hit one LDS bank
     // (measured: 720 conflict cycles per wave-timestep, i.e. all of SQ_LDS_BANK_CONFLICT).

@@ -47,7 +47,11 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               // put four waves on a SIMD (256x4: two)
                               {512, 2, false, "wg512x2s"},
                               // 128 < N <= 256, many windows: still one wave per window, four particles per lane
-                              {64, 4, true, "wg64x4"} };
+                              {64, 4, true, "wg64x4"},
+                              // 1024 < N <= 4096 (SVM fp64, one workgroup per CU by LDS): fewer, wider threads
+                              {512, 8, false, "wg512x8s"}, {256, 16, false, "wg256x16s"},
+                              // one wave per window, single state buffer
+                              {64, 2, false, "wg64x2s"}, {64, 4, false, "wg64x4s"} };
 constexpr int kLds4096Variant = 4, kTinyVariant = 5, kGarchVariant = 6, kTiny4Variant = 7;
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -341,6 +345,7 @@ int elementwise_pass(pfg_ctx *ctx, const pfg_problem &q, const double *theta_dev
 // ======================================================================================
 // ---- caller-registered pinned host ranges (pfg_host_register) -------------------------------------
 namespace {
+constexpr size_t kDirectMinDoubles = (size_t)1 << 16;     // inputs at least this long are staged from registered pages directly
 struct HostRange { const char *lo, *hi; };
 std::mutex g_host_mu;
 std::vector<HostRange> g_host_ranges;
@@ -558,8 +563,24 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     const int NS = state_dim(model), H = stat_dim(model), P = theta_dim(model);
 
     // ---- validate + size ------------------------------------------------------------
-    size_t n_in = 0, n_out = 0, n_work = 0;
+    // n_in: doubles of the device input arena; n_host: doubles of the pinned staging arena -- inputs shared by many
+    // windows of the batch (same pointer and length) count once in both, inputs that lie in caller-registered
+    // pinned memory need device space but no staging space (same decisions as `put` / `put_shared` below)
+    size_t n_in = 0, n_host = 0, n_out = 0, n_work = 0;
     int n_max = 0;
+    std::unordered_map<const double *, size_t> sized_shared;
+    auto size_in = [&](const double *src, size_t n) {
+        if (!src || n == 0) return;
+        n_in += n;
+        if (!(n >= kDirectMinDoubles && host_registered(src, n * 8))) n_host += n;
+    };
+    auto size_shared = [&](const double *src, size_t n) {
+        if (!src || n == 0) return;
+        auto it = sized_shared.find(src);
+        if (it != sized_shared.end() && it->second == n) return;
+        sized_shared[src] = n;
+        size_in(src, n);
+    };
     for (int b = 0; b < B; ++b) {
         const pfg_problem &q = ps[b];
         std::string id = "problem " + std::to_string(b) + ": ";
@@ -616,13 +637,28 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         }
         n_max = q.N > n_max ? q.N : n_max;
         const int nw = q.weights ? (q.tL < q.T ? q.tL : q.T) - q.t1 : 0;
-        n_in += (size_t)q.T + (nw > 0 ? nw : 0) + PFG_MAX_THETA;
-        if (rng == PFG_RNG_REPLAY) n_in += (q.z0 ? (size_t)q.N : 0) + 2 * (size_t)q.T * q.N;
-        if (q.init_x) n_in += (size_t)q.N * (NS + 1) + (q.init_stats ? (size_t)q.N * H : 0);
-        if (q.smoother == PFG_SMOOTHER_PARIS && rng == PFG_RNG_REPLAY)
-            n_in += (size_t)q.T * q.Ntilde * q.N * (1 + 2 * (size_t)q.max_accept_reject);
+        size_shared(q.y, (size_t)q.T);
+        size_shared(q.weights, nw > 0 ? (size_t)nw : 0);
+        n_in += PFG_MAX_THETA + (q.step ? 1 : 0);
+        n_host += PFG_MAX_THETA + (q.step ? 1 : 0);
+        if (rng == PFG_RNG_REPLAY) {
+            size_in(q.z0, (size_t)q.N);
+            size_in(q.u, (size_t)q.T * q.N);
+            size_in(q.z, (size_t)q.T * q.N);
+        }
+        if (q.init_x) {
+            size_in(q.init_x, (size_t)q.N * NS);
+            size_in(q.init_logw, (size_t)q.N);
+            size_in(q.init_stats, (size_t)q.N * H);
+        }
+        if (q.smoother == PFG_SMOOTHER_PARIS && rng == PFG_RNG_REPLAY) {
+            const size_t pool = (size_t)q.T * q.Ntilde * q.max_accept_reject * q.N;
+            size_in(q.paris_idx_u, pool);
+            size_in(q.paris_acc_u, pool);
+            size_in(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
+        }
         if (q.stat == PFG_STAT_PREDICTIVE && rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM)
-            n_in += (size_t)q.T * (q.num_steps_ahead + 1) * q.N;
+            size_in(q.pred_z, (size_t)q.T * (q.num_steps_ahead + 1) * q.N);
         const pfg_result &r = rs[b];
         n_out += PFG_OUT_DOUBLES + (q.stat == PFG_STAT_PREDICTIVE ? PFG_MAX_PRED : 0);
         if (r.x_T) n_out += (size_t)q.N * NS;
@@ -683,26 +719,43 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     PFG_HIP(ctx, ctx->desc.ensure((size_t)B * sizeof(pfg_dev_problem)));
     if (n_scratch) PFG_HIP(ctx, ctx->scratch.ensure(n_scratch));
     if (n_work) PFG_HIP(ctx, ctx->work.ensure(n_work * 8));
+    double *hin = nullptr;
     try {
-        if (ctx->h_in.ensure(n_in) != hipSuccess || ctx->h_out.ensure(n_out) != hipSuccess) throw std::bad_alloc();
+        if (ctx->h_in.ensure(n_host) == hipSuccess) {
+            hin = ctx->h_in.data();
+        } else {
+            // the runtime refuses to page-lock that much: stage from pageable memory (slower copies, same result)
+            (void)hipGetLastError();
+            ctx->h_in_pageable.resize(n_host);
+            hin = ctx->h_in_pageable.data();
+        }
+        if (ctx->h_out.ensure(n_out) != hipSuccess) throw std::bad_alloc();
         ctx->h_desc.assign(B, pfg_dev_problem{});
     } catch (const std::bad_alloc &) {
         return fail(ctx, PFG_ERR_NOMEM, "pfg_run_batch: out of host memory");
     }
 
     // ---- pack ---------------------------------------------------------------------------
-    double *hin = ctx->h_in.data();
     const double *din = static_cast<const double *>(ctx->in.ptr);
     double *dout = static_cast<double *>(ctx->out.ptr);
-    size_t oi = 0, oo = 0;
+    size_t oi = 0, oh = 0, oo = 0;       // offsets into the device input arena, the host staging arena, the output arena
     // big inputs that lie in caller-registered pinned memory (pfg_host_register) go to the device straight
-    // from there; everything else is packed into the library's pinned arena and staged in one copy
-    struct Direct { size_t at; const double *src; size_t n; };
-    std::vector<Direct> direct;
+    // from there; everything else is packed into the library's staging arena.  `copies` = the H2D transfers:
+    // runs of packed pieces (contiguous on both sides) and the direct pieces.
+    struct Copy { size_t at; const double *src; size_t n; bool packed; };
+    std::vector<Copy> copies;
     auto put = [&](const double *src, size_t n) -> const double * {
         if (!src || n == 0) return nullptr;
-        if (n >= (size_t)(1 << 16) && host_registered(src, n * 8)) direct.push_back({oi, src, n});
-        else std::memcpy(hin + oi, src, n * 8);
+        if (n >= kDirectMinDoubles && host_registered(src, n * 8)) {
+            copies.push_back({oi, src, n, false});
+        } else {
+            std::memcpy(hin + oh, src, n * 8);
+            if (!copies.empty() && copies.back().packed && copies.back().src + copies.back().n == hin + oh && copies.back().at + copies.back().n == oi)
+                copies.back().n += n;                     // extends the current packed run
+            else
+                copies.push_back({oi, hin + oh, n, true});
+            oh += n;
+        }
         const double *d = din + oi;
         oi += n;
         return d;
@@ -797,6 +850,11 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         d.rec_z0 = take(r.rec_z0 != nullptr, q.N);
         d.rec_ud = take(r.rec_ud != nullptr, (size_t)q.T * q.N);
         d.step_ctr = nullptr;
+        if (q.step) {       // the step counter of this window, as a resident chain would read it from HBM
+            double slot;
+            std::memcpy(&slot, &q.step, sizeof slot);
+            d.step_ctr = reinterpret_cast<const uint64_t *>(put(&slot, 1));
+        }
         d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
                               : nullptr;
         if (predictive) d.pred_scratch = static_cast<char *>(d.scratch) + (scratch_each - pred_each);
@@ -807,20 +865,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     }
 
     // ---- stage, launch, fetch -----------------------------------------------------------
-    if (direct.empty()) {
-        PFG_HIP(ctx, hipMemcpyAsync(ctx->in.ptr, hin, oi * 8, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        // the packed pieces between the direct ones, then the direct ones from the caller's pinned pages
-        size_t at = 0;
-        for (const Direct &dd : direct) {
-            if (dd.at > at)
-                PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + at, hin + at, (dd.at - at) * 8, hipMemcpyHostToDevice, ctx->stream));
-            PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + dd.at, dd.src, dd.n * 8, hipMemcpyHostToDevice, ctx->stream));
-            at = dd.at + dd.n;
-        }
-        if (oi > at)
-            PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + at, hin + at, (oi - at) * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (oi > n_in || oh > n_host) return fail(ctx, PFG_ERR_INVALID, "pfg_run_batch: internal sizing error");
+    for (const Copy &cp : copies)
+        PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + cp.at, cp.src, cp.n * 8, hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->h_desc.data(), (size_t)B * sizeof(pfg_dev_problem),
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));

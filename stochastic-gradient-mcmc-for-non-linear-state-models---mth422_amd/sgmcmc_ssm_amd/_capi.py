@@ -44,6 +44,7 @@ class Problem(C.Structure):
         ("paris_idx_u", _dp), ("paris_acc_u", _dp), ("paris_man_u", _dp),
         ("num_steps_ahead", C.c_int32), ("elementwise", C.c_int32),
         ("pred_z", _dp),
+        ("step", C.c_uint64),
     ]
 
 
@@ -72,7 +73,7 @@ PROBLEM_DTYPE = np.dtype([
     ("init_x", "u8"), ("init_logw", "u8"), ("init_stats", "u8"),
     ("Ntilde", "i4"), ("max_accept_reject", "i4"),
     ("paris_idx_u", "u8"), ("paris_acc_u", "u8"), ("paris_man_u", "u8"),
-    ("num_steps_ahead", "i4"), ("elementwise", "i4"), ("pred_z", "u8")], align=True)
+    ("num_steps_ahead", "i4"), ("elementwise", "i4"), ("pred_z", "u8"), ("step", "u8")], align=True)
 RESULT_DTYPE = np.dtype([
     ("mean_stat", "f8", (MAX_STAT,)), ("loglik", "f8"),
     ("x_T", "u8"), ("logw_T", "u8"), ("stats_T", "u8"),
@@ -353,6 +354,7 @@ class Context:
                     raise ValueError("replay stream z0 must have N entries")
             p.seed = int(q.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
             p.stream = int(q.get("stream", 0)) & 0xFFFFFFFFFFFFFFFF
+            p.step = int(q.get("step", 0)) & 0xFFFFFFFFFFFFFFFF
             keep.append(arrs)
             o = {}
             r = rs[b]
@@ -469,6 +471,7 @@ class Context:
         ps["max_accept_reject"] = [q.get("max_accept_reject", 0) for q in problems]
         ps["seed"] = np.array([int(q.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF for q in problems], dtype=np.uint64)
         ps["stream"] = np.array([int(q.get("stream", 0)) & 0xFFFFFFFFFFFFFFFF for q in problems], dtype=np.uint64)
+        ps["step"] = np.array([int(q.get("step", 0)) & 0xFFFFFFFFFFFFFFFF for q in problems], dtype=np.uint64)
         wlen = np.array([1 << 62 if t is None else t[2] for t in ws], dtype=np.int64)
         if np.any(wlen < tL - t1):
             raise ValueError("weights shorter than tL - t1")

@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld,eurus}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld,eurus,theta_grid}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -700,6 +700,85 @@ def make_eurus_fixtures():
     np.savez_compressed(os.path.join(HERE, "eurus.npz"), **out)
 
 
+
+# ----------------------------------------------------------------------------------------------------
+# theta grid (round 3): the kernel-level fixtures above use ONE parameter vector per model.  The reference's
+# own bias experiments sweep parameters (gradient_error_fig_scripts/lgssm_grad_compare.py:227-242), and some
+# formulas can only disagree away from the defaults -- LGSSM's optimal-kernel weight "assumes C = 1"
+# (models/lgssm/kernels.py:117-120), the stability edge |A| -> 0.9999 (what project_parameters allows),
+# Cholesky factors of 0.1 and 10, GARCH persistence phi -> 0.999 and mixing lambduh near 0 / 1
+# (models/garch/kernels.py:136-180).  Data are generated by the reference from the same parameters.
+# ----------------------------------------------------------------------------------------------------
+def garch_raw(mu, phi, lam, LRinv):
+    logit = lambda q: np.log(q / (1.0 - q))
+    return GARCHParameters(log_mu=np.log(mu), logit_phi=logit(phi), logit_lambduh=logit(lam), LRinv=np.eye(1) * LRinv)
+
+
+THETA_GRID = {
+    "svm": [("edgeA", lambda: SVMParameters(A=np.eye(1) * 0.9999, LQinv=np.eye(1) * 1.4, LRinv=np.eye(1) * 1.4)),
+            ("negA_LQ.1_LR10", lambda: SVMParameters(A=np.eye(1) * -0.9, LQinv=np.eye(1) * 0.1, LRinv=np.eye(1) * 10.0)),
+            ("LQ10_LR.1", lambda: SVMParameters(A=np.eye(1) * 0.5, LQinv=np.eye(1) * 10.0, LRinv=np.eye(1) * 0.1))],
+    "lgssm": [("C.3", lambda: lgssm_params(C=0.3)),
+              ("C1.7", lambda: lgssm_params(C=1.7)),
+              ("edgeA_LQ.1_LR10", lambda: LGSSMParameters(A=np.eye(1) * 0.9999, C=np.eye(1), LQinv=np.eye(1) * 0.1, LRinv=np.eye(1) * 10.0)),
+              ("negA_C1.7_LQ10_LR.1", lambda: LGSSMParameters(A=np.eye(1) * -0.5, C=np.eye(1) * 1.7, LQinv=np.eye(1) * 10.0, LRinv=np.eye(1) * 0.1))],
+    "garch": [("phi.999", lambda: garch_raw(1.0, 0.999, 0.5, 0.3 ** -0.5)),
+              ("lam.01", lambda: garch_raw(1.0, 0.9, 0.01, 0.3 ** -0.5)),
+              ("lam.99_LR10", lambda: garch_raw(1.0, 0.9, 0.99, 10.0)),
+              ("phi.5_LR.1", lambda: garch_raw(0.5, 0.5, 0.5, 0.1))],
+}
+
+
+def make_theta_grid_fixtures():
+    out, meta = {}, []
+    combos = [("svm", "prior"), ("garch", "prior"), ("garch", "optimal"), ("lgssm", "prior"), ("lgssm", "optimal")]
+    ci = 0
+    for model, kernel in combos:
+        cfg = MODEL_SETUP[model]
+        for gi, (tag, mk) in enumerate(THETA_GRID[model]):
+            p = mk()
+            np.random.seed(5000 + 17 * gi + len(model))
+            data = cfg["gen"](T=64, parameters=p)
+            pm, pv = prior_x(model, p, data)
+            # traced tiny cases: every step's particles / log-weights / statistics
+            N, T, t1, tL = 24, 12, 2, 10
+            y = data["observations"][:T]
+            weights = 1.0 + 0.5 * np.arange(tL - t1)
+            for pf, lam in [("poyiadjis_N", None), ("nemeth", 0.7), ("filter", None)]:
+                seed = 7000 + ci
+                res = run_window(model, kernel, pf, "score", p, y, N, t1, tL, weights, pm, pv, seed, save_all=True, lambduh=lam)
+                key = "g{0}".format(len(meta))
+                meta.append(dict(key=key, model=model, kernel=kernel, pf=pf, stat="score", lambduh=lam, N=N, T=T, t1=t1,
+                                 tL=tL, seed=seed, prior_mean=pm, prior_var=pv, traced=True, tag=tag))
+                out[key + "/y"] = y.reshape(-1)
+                out[key + "/theta"] = theta_of(model, p)
+                out[key + "/weights"] = weights
+                for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+                    out[key + "/" + name] = np.asarray(res[name], dtype=float)
+                if pf != "filter":
+                    out[key + "/mean_statistic"] = res["mean_statistic"]
+                ci += 1
+            # window-level case at the bench particle count: S = 16, B = 4 with importance weights
+            N, T, t1, tL = 1000, 24, 4, 20
+            y = data["observations"][30:30 + T]
+            weights = np.linspace(40.0, 61.0, tL - t1)
+            seed = 7000 + ci
+            res = run_window(model, kernel, "poyiadjis_N", "score", p, y, N, t1, tL, weights, pm, pv, seed)
+            key = "g{0}".format(len(meta))
+            meta.append(dict(key=key, model=model, kernel=kernel, pf="poyiadjis_N", stat="score", lambduh=None, N=N, T=T,
+                             t1=t1, tL=tL, seed=seed, prior_mean=pm, prior_var=pv, traced=False, tag=tag))
+            out[key + "/y"] = y.reshape(-1)
+            out[key + "/theta"] = theta_of(model, p)
+            out[key + "/weights"] = weights
+            out[key + "/loglikelihood_estimate"] = np.float64(res["loglikelihood_estimate"])
+            out[key + "/mean_statistic"] = res["mean_statistic"]
+            out[key + "/log_weights"] = res["log_weights"]
+            ci += 1
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "theta_grid.npz"), **out)
+    print("theta grid:", len(meta), "cases")
+
+
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY", "")
     if only in ("", "eurus"):
@@ -722,6 +801,8 @@ if __name__ == "__main__":
         make_latent_fixtures()
     if only in ("", "predictive"):
         make_predictive_fixtures()
-    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz"):
+    if only in ("", "theta_grid"):
+        make_theta_grid_fixtures()
+    for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz", "theta_grid.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -83,6 +83,18 @@ CASES = [
     ("garch", "optimal", "poyiadjis_N", 1.0, 1000, 24, (4, 20, True), "wg256x4s", (256, 4, "fixed32")),
     # config 4: SVM N=4000, LDS-resident 1024 x 4
     ("svm", "prior", "poyiadjis_N", 1.0, 4000, 1000, None, "wg1024x4s", (1024, 4, "fixed32")),   # full size
+    # the same 4096 LDS slots in fewer, wider threads (no 128-VGPR cap): 512 x 8 and 256 x 16
+    ("svm", "prior", "poyiadjis_N", 1.0, 4000, 1000, None, "wg512x8s", (512, 8, "fixed32")),    # full size
+    ("svm", "prior", "nemeth", 0.95, 4096, 30, (5, 25, True), "wg512x8s", (512, 8, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 2049, 20, None, "wg512x8s", (512, 8, "fixed32")),
+    ("svm", "prior", "poyiadjis_N", 1.0, 4000, 60, None, "wg256x16s", (256, 16, "fixed32")),
+    ("svm", "prior", "filter", 1.0, 3333, 20, None, "wg256x16s", (256, 16, "fixed32")),
+    # one wave per window on a single state buffer
+    ("lgssm", "optimal", "poyiadjis_N", 1.0, 100, 200, None, "wg64x2s", (64, 2, "fixed32")),
+    ("lgssm", "prior", "nemeth", 0.9, 128, 50, (5, 40, True), "wg64x2s", (64, 2, "fixed32")),
+    ("garch", "optimal", "poyiadjis_N", 1.0, 77, 40, None, "wg64x2s", (64, 2, "fixed32")),
+    ("lgssm", "optimal", "poyiadjis_N", 1.0, 200, 80, None, "wg64x4s", (64, 4, "fixed32")),
+    ("svm", "prior", "filter", 1.0, 256, 40, None, "wg64x4s", (64, 4, "fixed32")),
     # config 5: SVM N=10000, S=16 B=4 window, large-N kernel (fp64 CDF)
     ("svm", "prior", "poyiadjis_N", 1.0, 10000, 24, (4, 20, True), "big16384", (16384, 1, "f64_uniform")),
     ("svm", "prior", "poyiadjis_N", 1.0, 9001, 30, None, "big16384", (16384, 1, "f64_uniform")),
