@@ -221,6 +221,16 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
  * n_max = the largest N in the batch (selects the kernel variant). */
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+/* pfg_launch_device / pfg_launch_device_smoother are the PRODUCTION launches: for the plain (NEMETH / FILTER)
+ * LDS-resident kernels of the DEVICE generator they run an instantiation with the trace instrumentation compiled
+ * out, which IGNORES the trace_x / trace_logw / trace_stats / trace_ll / trace_anc / rec_* fields of the
+ * descriptors (out / final_* / stamps are honoured).  pfg_launch_device_traced runs the twin that honours them
+ * (save_all trajectories, recorded generator draws); same arguments as pfg_launch_device_smoother.  Both twins
+ * return bitwise the same `out` record for the same descriptor (tests/test_gpu_device_replay.py).
+ * pfg_last_traced: 1 if the latest launch through the context honoured trace buffers, 0 if not. */
+int pfg_launch_device_traced(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
+                             int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+int pfg_last_traced(pfg_ctx *ctx);
 /* as pfg_launch_device for a batch whose descriptors all have smoother = `smoother`
  * (PFG_SMOOTHER_PARIS, _NEMETH_SYSTEMATIC and _POYIADJIS_N2 have their own kernel instantiations;
  * the plain entry point serves NEMETH / FILTER) */

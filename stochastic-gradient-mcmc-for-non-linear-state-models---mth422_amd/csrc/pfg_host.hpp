@@ -63,6 +63,7 @@ struct pfg_ctx {
     std::vector<double> h_in_pageable;   // staging when the pinned arena cannot be had (hipHostMalloc refused)
     std::vector<pfg_dev_problem> h_desc;
     const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched
+    bool last_traced = false;            // ... and whether that was a trace-honouring instantiation
     // largest dynamic-LDS size hipFuncAttributeMaxDynamicSharedMemorySize has been set to, per kernel: the
     // attribute is per (function, device) and a context is bound to one device
     std::unordered_map<const void *, size_t> lds_set;
@@ -91,6 +92,6 @@ constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVar
 // Launch of every kernel of one (model, proposal kernel, generator): defined (and explicitly
 // instantiated) in pfg_inst_*.hip via pfg_launch.hpp, declared here for the dispatcher in pfgrad.hip.
 template <int MODEL, int KERNEL, int RNG>
-int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st);
+int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced);
 
 }  // namespace pfg_host

@@ -21,50 +21,49 @@ namespace pfg_host {
         }                                                                                                 \
     } while (0)
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
-int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP>;
+// traced = the descriptors may carry trace_* / rec_* buffers: the TRACE = true instantiation.  The REPLAY units exist
+// as TRACE = true only (parity path, not the timed one).
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool TRACE>
+int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, pfg::MODE_PLAIN, TRACE>;
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
     PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
 }
-
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
+int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
+    if constexpr (RNG == PFG_RNG_DEVICE) {
+        if (!traced) return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false>(ctx, n_max, B, dp, st);
+    }
+    return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, true>(ctx, n_max, B, dp, st);
+}
 template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+int launch_v(pfg_ctx *ctx, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
     switch (v) {
-        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st);
-        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st);
-        case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st);
-        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st);
-        case 5: return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, true>(ctx, n_max, B, dp, st);
+        case 0: return launch_one<MODEL, KERNEL, REAL, 256, 1, RNG, true>(ctx, n_max, B, dp, st, traced);
+        case 1: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, true>(ctx, n_max, B, dp, st, traced);
+        case 2: return launch_one<MODEL, KERNEL, REAL, 256, 4, RNG, false>(ctx, n_max, B, dp, st, traced);
+        case 3: return launch_one<MODEL, KERNEL, REAL, 1024, 1, RNG, true>(ctx, n_max, B, dp, st, traced);
+        case 5: return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, true>(ctx, n_max, B, dp, st, traced);
         case 4:
-            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st);
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 1024, 4, RNG, false>(ctx, n_max, B, dp, st, traced);
             break;
         case 7:
-            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, true>(ctx, n_max, B, dp, st);
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, true>(ctx, n_max, B, dp, st, traced);
             break;
         case 6:
             if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_GARCH && sizeof(REAL) == 8)
-                return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, false>(ctx, n_max, B, dp, st);
+                return launch_one<MODEL, KERNEL, REAL, 512, 2, RNG, false>(ctx, n_max, B, dp, st, traced);
             break;
         // one wave per window on ONE state buffer (a wave's LDS accesses execute in order: the gather of a step is
         // over before its stores are issued, the fourth "barrier" is free) -- half the LDS per window
-        case 10:
-            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, false>(ctx, n_max, B, dp, st);
-            break;
-        case 11:
-            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, false>(ctx, n_max, B, dp, st);
-            break;
-        // 1024 < N <= 4096, SVM fp64: the same 4096 LDS slots in 512 / 256 threads (no 128-VGPR cap)
         case 8:
-            if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_SVM && sizeof(REAL) == 8)
-                return launch_one<MODEL, KERNEL, REAL, 512, 8, RNG, false>(ctx, n_max, B, dp, st);
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 2, RNG, false>(ctx, n_max, B, dp, st, traced);
             break;
         case 9:
-            if constexpr (RNG == PFG_RNG_DEVICE && MODEL == PFG_MODEL_SVM && sizeof(REAL) == 8)
-                return launch_one<MODEL, KERNEL, REAL, 256, 16, RNG, false>(ctx, n_max, B, dp, st);
+            if constexpr (RNG == PFG_RNG_DEVICE) return launch_one<MODEL, KERNEL, REAL, 64, 4, RNG, false>(ctx, n_max, B, dp, st, traced);
             break;
     }
     return fail(ctx, PFG_ERR_UNSUPPORTED, "no kernel variant");
@@ -164,7 +163,7 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 // -ffp-contract=fast (no operation-order parity to keep there), the REPLAY units with
 // -ffp-contract=off (the reference's NumPy operation order).
 template <int MODEL, int KERNEL, int RNG>
-int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
     if (v == kVariantSystematic) {
         if constexpr (RNG != PFG_RNG_DEVICE) {
             return fail(ctx, PFG_ERR_UNSUPPORTED, "systematic resampling needs the DEVICE rng");
@@ -193,8 +192,8 @@ int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_p
         if (dtype == PFG_F64) return launch_mem<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
         return launch_mem<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
     }
-    if (dtype == PFG_F64) return launch_v<MODEL, KERNEL, double, RNG>(ctx, v, n_max, B, dp, st);
-    return launch_v<MODEL, KERNEL, float, RNG>(ctx, v, n_max, B, dp, st);
+    if (dtype == PFG_F64) return launch_v<MODEL, KERNEL, double, RNG>(ctx, v, n_max, B, dp, st, traced);
+    return launch_v<MODEL, KERNEL, float, RNG>(ctx, v, n_max, B, dp, st, traced);
 }
 
 }  // namespace pfg_host

@@ -64,7 +64,8 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
 #define PFG_OCC64 4
 #endif
 // 4096 particle slots in fewer than 1024 threads (N <= 4096 state fills the LDS of a CU: ONE workgroup per CU
-// whatever its thread count): 512 threads = 2 waves per SIMD and 256 VGPRs, 256 threads = 1 wave per SIMD and 512
+// whatever its thread count): 512 threads = 2 waves per SIMD and 256 VGPRs, 256 threads = 1 wave per SIMD and 512.
+// (A/B instantiations of round 3, slower than 1024 x 4 and no longer built: see the variant table in pfgrad.hip.)
 __host__ __device__ constexpr bool occ_lds4096(int NT, int PPT) { return NT * PPT == 4096 && NT < 1024; }
 __host__ __device__ constexpr int occ_max(int NT, int PPT, size_t real, bool PP, bool dev4 = false) {
     if (occ_lds4096(NT, PPT)) return NT == 512 ? 2 : 1;
@@ -103,6 +104,19 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 // level cost more than the round trips they save; the children of a step kept in registers and written behind
 // barrier 1 of the NEXT step (every wave is past its gathers by then: three barriers per timestep on one buffer, the
 // gathers' latency overlapped with the generator calls): SVM +5.5 % (32 spilled registers), GARCH +1 %, N = 4000 +2 %.
+// TRACE (template parameter of pf_reg_kernel): the instantiation honours the trace_* / rec_* buffers of its
+// descriptors (save_all trajectories, recorded generator draws: tests, elementwise statistics).  TRACE = false is
+// the production twin of the plain device-generator kernels: the same code with every trace / record test compiled
+// out of the T-loop -- each was a scalar load of a descriptor field plus a wait on the critical path of every
+// timestep, and their address registers cost spills (measured: -5 % kernel time on BASELINE configs[1], -12 % on
+// config 3, -6 % on config 1, -2 % on config 4).  tests/test_gpu_device_replay.py replays the TRACE = true twin from its
+// recorded draws and asserts that the TRACE = false twin returns bitwise the same statistics for the same key.
+// A/B experiment switch (diagnostic builds only; default = production):
+//  PFG_EXP_PLAIN    compile the filter / lambda != 1 / no-statistic cases out (Poyiadjis O(N) score only)
+#ifndef PFG_EXP_PLAIN
+#define PFG_EXP_PLAIN 0
+#endif
+#define PFG_TR(p) (TRACE && (p))
 #ifdef PFG_FAST_ALGEBRA
 #ifndef PFG_OPT_LAZYLL
 #define PFG_OPT_LAZYLL 1
@@ -131,7 +145,7 @@ __host__ __device__ constexpr bool occ_dev4(int MODEL, int NT, int PPT, int RNG,
     return PFG_OCC4 && MODEL == PFG_MODEL_SVM && NT == 256 && PPT == 4 && !PP && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0, bool TRACE = true>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_min(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE)), occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_max(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE))))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr bool PARIS = (MODE == MODE_PARIS);
     constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
@@ -148,9 +162,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const int NL = fast_layout(NT, PP) ? NT * PPT : (N + WAVE - 1) / WAVE * WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
-    const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
+    const bool is_filter = !PFG_EXP_PLAIN && (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = PFG_EXP_PLAIN ? (int)PFG_STAT_SCORE : P.stat;
+    const double lam_d = PFG_EXP_PLAIN ? 1.0 : is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const double *__restrict__ const yv = P.y;
@@ -212,8 +226,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph_prev = __builtin_amdgcn_s_memtime();
 #define PFG_PH(i) { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_now - ph_prev; ph_prev = ph_now; }
+#define PFG_MARK(s)
+#elif defined(PFG_ISA_MARKERS)
+    // tools/isa_histogram.py: phase boundaries and rarely-executed regions as comments in the ISA listing
+#define PFG_PH(i) asm volatile("; PFG_PHASE " #i);
+#define PFG_MARK(s) asm volatile("; PFG_MARK " s);
 #else
 #define PFG_PH(i)
+#define PFG_MARK(s)
 #endif
 
     LaneRng rng = {};
@@ -260,13 +280,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 } else {
                     const double z = (RNG == PFG_RNG_REPLAY) ? P.z0[i] : (double)z0[k];
                     x[0] = (REAL)(P.prior_mean + sd * z);
-                    if (RNG == PFG_RNG_DEVICE && P.trace_x && P.rec_z0) P.rec_z0[i] = z;
+                    if (RNG == PFG_RNG_DEVICE && PFG_TR(P.trace_x) && P.rec_z0) P.rec_z0[i] = z;
                 }
 #pragma unroll
                 for (int d = 0; d < NS; ++d) cur[(size_t)d * NL + i] = x[d];
 #pragma unroll
                 for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NL + i] = s[h];
-                if (P.trace_x) {
+                if (PFG_TR(P.trace_x)) {
 #pragma unroll
                     for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
                     P.trace_logw[i] = (double)lw[k];
@@ -321,6 +341,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
         for (int k = 0; k < PPT; ++k) cs[k] = (double)mth.exp((REAL)(lw[k] - (REAL)m));   // exp(-inf) = 0
         if (needS) {
+            PFG_MARK("cold needS")
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double part = 0.0;
@@ -422,6 +443,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             invW = uniform_f64(1.0 / W);
         }
         if (needS) {
+            PFG_MARK("cold needS")
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double acc = 0.0;
@@ -433,13 +455,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         // log-likelihood increment of the step that produced these weights
         // (buffered_smoother.py:124-126): log(mean(exp(logw))) = m + log(W/N).  Wave 0 only.
         if (wave == 0) {
+            PFG_MARK("w0.25 wave0-loglik")
             const bool counts = t > 0 && (t - 1) >= t1 && (t - 1) < tL;
             if (LAZYLL) {
                 const bool mine = lane == (t & (WAVE - 1));
                 ll_W = mine ? W : ll_W;
                 ll_w = mine ? (counts ? wt_prev : 0.0) : ll_w;
                 ll_m = mine ? (float)m : ll_m;          // m is an f32 value
-                if ((t & (WAVE - 1)) == WAVE - 1 || t == T || P.trace_ll) {
+                if ((t & (WAVE - 1)) == WAVE - 1 || t == T || PFG_TR(P.trace_ll)) {
+                    PFG_MARK("cold loglik-flush")
                     const double term = ll_w * ((double)ll_m + (double)mth.log((REAL)(ll_W * invN)));
                     ll = uniform_f64(ll + wave_sum(term));
                     ll_w = 0.0;
@@ -447,9 +471,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             } else if (counts) {
                 ll = uniform_f64(ll + wt_prev * (m + log(W / (double)N)));
             }
-            if (P.trace_ll && tid == 0) P.trace_ll[t] = ll;
+            if (PFG_TR(P.trace_ll) && tid == 0) P.trace_ll[t] = ll;
         }
         if (is_filter && t > 0) {
+            PFG_MARK("cold filter")
 #pragma unroll
             for (int h = 0; h < H; ++h) filt[h] = uniform_f64(filt[h] + S[h]);
         }
@@ -501,7 +526,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             uint32_t ua[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) ua[k] = rng.next();
-            if (P.trace_x && P.rec_u) {           // test instrumentation: the words this launch searched with
+            if (PFG_TR(P.trace_x) && P.rec_u) {           // test instrumentation: the words this launch searched with
 #pragma unroll
                 for (int k = 0; k < PPT; ++k)
                     if (valid[k]) P.rec_u[(size_t)t * N + k * NT + tid] = ua[k];
@@ -579,6 +604,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         // ---- (F) gather parents, (G) propose / weight / statistic, (H) publish children ---
         auto slots = [&](auto stat_tag) {
             constexpr int STAT = decltype(stat_tag)::value;
+            if (STAT != PFG_STAT_SCORE) { PFG_MARK("cold sufficient-statistics") }
             REAL xp[PPT][NS], sp[PPT][H];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -592,7 +618,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             PFG_PH(8)
             if (RNG != PFG_RNG_REPLAY) {
                 draw_normals(zz);
-                if (P.trace_x && P.rec_z) {
+                if (PFG_TR(P.trace_x) && P.rec_z) {
 #pragma unroll
                     for (int k = 0; k < PPT; ++k)
                         if (valid[k]) P.rec_z[(size_t)t * N + k * NT + tid] = (double)zz[k];
@@ -603,6 +629,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             // LDS cell and weight 0) -- the PPT particle chains stay in one basic block for the scheduler.
             auto children = [&](auto upd_tag) {
                 constexpr int UPD = decltype(upd_tag)::value;      // 0 plain + statistic, 1 plain, no statistic, 2 general
+                if (UPD == 1) { PFG_MARK("cold children-outside-window") }
+                if (UPD == 2) { PFG_MARK("cold children-general") }
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     REAL xn[NS], add[H], lwn;
@@ -869,7 +897,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const int Jk = valid[k] ? Jres[k * NT + tid] : 0;
-                    if (P.trace_x && P.trace_paris_J && valid[k])
+                    if (PFG_TR(P.trace_x) && P.trace_paris_J && valid[k])
                         P.trace_paris_J[((size_t)t * Nt + j) * N + k * NT + tid] = Jk;
                     REAL xJ[NS], aj[H];
 #pragma unroll
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             if (stat == PFG_STAT_SCORE) slots(std::integral_constant<int, PFG_STAT_SCORE>{});
             else slots(std::integral_constant<int, PFG_STAT_SUFF>{});
         }
-        if (P.trace_x) {
+        if (PFG_TR(P.trace_x)) {
             // own children back from LDS (written by this thread: no barrier needed)
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -1012,6 +1040,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     }
 #endif
 #undef PFG_PH
+#undef PFG_MARK
 
     // ---- outputs --------------------------------------------------------------------
     if (RNG == PFG_RNG_REPLAY && P.out) {

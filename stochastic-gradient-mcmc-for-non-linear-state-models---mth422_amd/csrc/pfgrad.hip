@@ -11,21 +11,21 @@
 using namespace pfg_host;
 
 namespace pfg_host {
-extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
+extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
 
 template <int MODEL, int KERNEL>
-int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (rng == PFG_RNG_REPLAY) return launch_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, v, n_max, B, dp, st);
-    return launch_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, v, n_max, B, dp, st);
+int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
+    if (rng == PFG_RNG_REPLAY) return launch_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, v, n_max, B, dp, st, traced);
+    return launch_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, v, n_max, B, dp, st, traced);
 }
 }  // namespace pfg_host
 
@@ -48,11 +48,16 @@ const Variant kVariants[] = { {256, 1, true, "wg256x1"}, {256, 4, true, "wg256x4
                               {512, 2, false, "wg512x2s"},
                               // 128 < N <= 256, many windows: still one wave per window, four particles per lane
                               {64, 4, true, "wg64x4"},
-                              // 1024 < N <= 4096 (SVM fp64, one workgroup per CU by LDS): fewer, wider threads
-                              {512, 8, false, "wg512x8s"}, {256, 16, false, "wg256x16s"},
                               // one wave per window, single state buffer
                               {64, 2, false, "wg64x2s"}, {64, 4, false, "wg64x4s"} };
+// Measured and not kept (round 3, BASELINE config 4, 512 chains, ms per launch): the 4096 LDS slots of N <= 4096 in
+// fewer, wider threads -- 512 x 8 (2 waves per SIMD, 251 VGPRs, no spills) 12.99, 256 x 16 (1 wave per SIMD, 256 VGPRs +
+// 176 AGPRs) 16.14, against 12.73 for 1024 x 4 at its 128-VGPR cap (16 spilled VGPRs): LDS holds ONE such workgroup per
+// CU, so its own 16 waves are all the latency hiding a CU has, and they are worth more than the registers.
 constexpr int kLds4096Variant = 4, kTinyVariant = 5, kGarchVariant = 6, kTiny4Variant = 7;
+// device generator: the one-wave variants on a single state buffer (half the LDS per window: 18 instead of 11 windows
+// per CU for LGSSM N = 100; 16384 windows of BASELINE config 1 in 1.86 instead of 2.25 ms)
+constexpr int kTinySingleVariant = 8, kTiny4SingleVariant = 9;
 constexpr int kLatencyVariant = 3, kLatencyBatch = 64;
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -91,10 +96,10 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
     // a lone window is quicker on the four waves of wg256x1 (0.34 vs 0.38 ms)
     if (n_max <= 128 && batch > kLatencyBatch &&
         lds_bytes(model, dtype, rng, kVariants[kTinyVariant], n_max) <= kLdsLimit)
-        return kTinyVariant;
+        return rng == PFG_RNG_DEVICE ? kTinySingleVariant : kTinyVariant;
     if (n_max > 128 && n_max <= 256 && batch > kLatencyBatch && rng == PFG_RNG_DEVICE &&
         lds_bytes(model, dtype, rng, kVariants[kTiny4Variant], n_max) <= kLdsLimit)
-        return kTiny4Variant;
+        return kTiny4SingleVariant;
     if (batch <= kLatencyBatch && n_max > 256 && n_max <= 1024 &&
         lds_bytes(model, dtype, rng, kVariants[kLatencyVariant], n_max) <= kLdsLimit)
         return kLatencyVariant;
@@ -134,9 +139,11 @@ int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
     return PFG_OK;
 }
 
+// traced: the descriptors may carry trace_* / rec_* buffers (the plain LDS-resident device-generator kernels exist
+// as a production twin that ignores them, see pfg_reg_kernel.hpp; every other kernel always honours them)
 int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
              const pfg_dev_problem *dp, hipStream_t st, int smoother = PFG_SMOOTHER_NEMETH,
-             bool force_mem = false) {
+             bool force_mem = false, bool traced = true) {
     int rc = check_combo(ctx, model, kernel, dtype, rng);
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
@@ -161,13 +168,14 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                         : v == kVariantParis ? (n_max <= 256 ? "paris256x1" : n_max <= 1024 ? "paris256x4" : "paris_mem1024")
                         : v == kVariantSystematic ? "systematic256x4"
                         : (n_max <= 256 ? "n2_256x1" : "n2_256x4");
-    if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
+    ctx->last_traced = traced || v < 0 || rng == PFG_RNG_REPLAY;
+    if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
     if (model == PFG_MODEL_GARCH) {
-        if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
-        return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st);
+        if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
+        return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
     }
-    if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st);
-    return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st);
+    if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
+    return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
 }
 
 // ---- SGLD update for resident chains ---------------------------------------------------
@@ -438,6 +446,8 @@ void pfg_destroy(pfg_ctx *ctx) {
 
 const char *pfg_last_variant(pfg_ctx *ctx) { return ctx ? ctx->last_variant : "none"; }
 
+int pfg_last_traced(pfg_ctx *ctx) { return ctx ? (ctx->last_traced ? 1 : 0) : -1; }
+
 void *pfg_ctx_stream(pfg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int pfg_synchronize(pfg_ctx *ctx) {
@@ -469,7 +479,17 @@ int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, i
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device: dev_probs is NULL");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream);
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, PFG_SMOOTHER_NEMETH, false, false);
+}
+
+int pfg_launch_device_traced(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother, int n_max, int B,
+                             const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_traced: dev_probs is NULL");
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N2)
+        return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother, false, true);
 }
 
 int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother, int n_max,
@@ -479,7 +499,7 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
     if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N2)
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother);
+    return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother, false, false);
 }
 
 int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum, const double *outs,
@@ -698,6 +718,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
+    bool traced = false;
+    for (int b = 0; b < B; ++b)
+        traced = traced || rs[b].trace_x || rs[b].trace_ll || rs[b].rec_u || rs[b].rec_z || rs[b].rec_z0 || rs[b].rec_ud || ps[b].elementwise;
     const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
     const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
     const bool predictive = ps[0].stat == PFG_STAT_PREDICTIVE;   // large-N kernel only (any N)
@@ -874,7 +897,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
                   ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC
                                : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
-                  predictive);
+                  predictive, traced);
     if (rc) return rc;
     for (int b = 0; b < B; ++b) {
         if (!ps[b].elementwise) continue;

@@ -120,7 +120,8 @@ DEV_PROBLEM_DTYPE = np.dtype([
 EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_last_error", "pfg_run", "pfg_run_batch",
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
-           "pfg_last_variant", "pfg_legacy_streams", "pfg_host_register", "pfg_host_unregister")
+           "pfg_last_variant", "pfg_legacy_streams", "pfg_host_register", "pfg_host_unregister",
+           "pfg_launch_device_traced", "pfg_last_traced")
 
 _lib = None
 
@@ -182,6 +183,10 @@ def load_library():
     lib.pfg_ctx_stream.restype = C.c_void_p
     lib.pfg_launch_device_smoother.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
     lib.pfg_launch_device_smoother.restype = C.c_int
+    lib.pfg_launch_device_traced.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    lib.pfg_launch_device_traced.restype = C.c_int
+    lib.pfg_last_traced.argtypes = [C.c_void_p]
+    lib.pfg_last_traced.restype = C.c_int
     lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pfg_scratch_bytes.restype = C.c_int64
     lib.pfg_variant_name.argtypes = [C.c_int] * 5
@@ -497,6 +502,15 @@ class Context:
         self._check(self.lib.pfg_launch_device_smoother(
             self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], SMOOTHER[smoother], int(n_max),
             int(B), C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
+
+    def launch_device_traced(self, model, kernel, dtype, rng, smoother, n_max, B, dev_probs_ptr, stream_ptr=0):
+        """The launch that honours the trace_* / rec_* buffers of the descriptors (pfg_launch_device_traced)."""
+        self._check(self.lib.pfg_launch_device_traced(
+            self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], SMOOTHER[smoother], int(n_max),
+            int(B), C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
+
+    def last_traced(self):
+        return bool(self.lib.pfg_last_traced(self.handle))
 
     def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=0):
         """stream_ptr: a hipStream_t handle used as is (0 = HIP's default stream, which is also

@@ -305,11 +305,17 @@ class ChainEnsemble(object):
         return True
 
     # ------------------------------------------------------------------------------------
-    def launch_pf(self, stream=None):
+    def launch_pf(self, stream=None, traced=False):
         """Enqueue one particle-filter launch for all chains on `stream` (default: torch's
-        current stream).  Results land in self.out_dev[C, 8] (score columns, loglik)."""
+        current stream).  Results land in self.out_dev[C, 8] (score columns, loglik).
+        traced=True runs the twin instantiation that honours trace_* / rec_* buffers a caller put into
+        the descriptors (tests, diagnostics); the production launch ignores them."""
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        if self.resampling == "systematic":
+        if traced:
+            self.ctx.launch_device_traced(self.model, self.kernel, self.dtype, "device",
+                                          "nemeth_systematic" if self.resampling == "systematic" else "nemeth",
+                                          self.N, self.C, self.desc_dev.data_ptr(), st)
+        elif self.resampling == "systematic":
             self.ctx.launch_device_smoother(self.model, self.kernel, self.dtype, "device", "nemeth_systematic",
                                             self.N, self.C, self.desc_dev.data_ptr(), st)
         else:

@@ -37,8 +37,8 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_struct_size(2) == _capi.DEV_PROBLEM_DTYPE.itemsize == 344
     assert lib.pfg_struct_size(99) == -1
     assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4s"
-    assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg64x2"         # N <= 128, throughput: one wave per window
-    assert lib.pfg_variant_name(0, 0, 0, 1, 200) == b"wg64x4"          # 128 < N <= 256, device generator, many windows
+    assert lib.pfg_variant_name(0, 0, 0, 1, 100) == b"wg64x2s"        # N <= 128, throughput: one wave per window
+    assert lib.pfg_variant_name(0, 0, 0, 1, 200) == b"wg64x4s"         # 128 < N <= 256, device generator, many windows
     assert lib.pfg_variant_name(0, 0, 0, 0, 200) == b"wg256x1"         # ... the REPLAY units
     assert lib.pfg_variant_name(0, 0, 0, 1, 1024) == b"wg256x4s"
     assert lib.pfg_variant_name(0, 0, 0, 0, 1025) == b"mem1024"       # N > 1024: state in HBM scratch

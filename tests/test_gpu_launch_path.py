@@ -11,8 +11,9 @@ descriptors.  Same kernels, different marshalling and keying -- so here
      for buffered windows sampled on the host and on the device; a wrong stream / t1 / tL / weights pointer /
      step in either path breaks the equality;
  (b) one chain of a ChainEnsemble launch at BASELINE's full size (SVM T = N = 1000, the bench instantiation
-     wg256x4s) gets record buffers in its descriptor and the CPU oracle replays that very launch from the
-     recorded draws (zero ancestor flips, rtol 1e-8) -- the reference's T-loop (particle_filters/
+     wg256x4s) gets record buffers in its descriptor; the production launch must ignore them, its trace-honouring
+     twin (same descriptors, same marshalling, `launch_pf(traced=True)`) must return bitwise the production
+     launch's result records, and the CPU oracle replays that launch from the recorded draws (zero ancestor flips, rtol 1e-8) -- the reference's T-loop (particle_filters/
      buffered_smoother.py:93-133, pf.py:138-181) on what sgmcmc_sampler.py:364-384 says a chain's gradient is.
 """
 import numpy as np
@@ -80,7 +81,7 @@ def _assert_launch_equals_run_batch(ens, step):
     return variant
 
 
-@pytest.mark.parametrize("model,N,variant", [("svm", 1000, "wg256x4s"), ("garch", 1000, "wg512x2s"), ("lgssm", 100, "wg64x2")])
+@pytest.mark.parametrize("model,N,variant", [("svm", 1000, "wg256x4s"), ("garch", 1000, "wg512x2s"), ("lgssm", 100, "wg64x2s")])
 def test_full_sequence_launch_is_run_batch_bitwise(model, N, variant):
     from sgmcmc_ssm_amd.ensemble import ChainEnsemble
     y = _series(model, 90)
@@ -140,10 +141,19 @@ def test_bench_launch_replayed_by_oracle_at_full_size():
     for k, t in buf.items():
         ens._desc[k][c] = t.data_ptr()
     ens.desc_dev.copy_(torch.from_numpy(ens._desc.view(np.uint8).reshape(ens.C, -1)))
+    # the production launch (what bench.py times) ignores the record buffers; its twin with the trace
+    # instrumentation compiled in honours them and must return bitwise the same result records
     ens.launch_pf()
     ens.synchronize()
-    assert ens.ctx.last_variant() == "wg256x4s"
+    assert ens.ctx.last_variant() == "wg256x4s" and not ens.ctx.last_traced()
+    production = ens.out_dev.cpu().numpy().copy()
+    assert not np.any(buf["rec_u"].cpu().numpy()) and not np.any(buf["trace_x"].cpu().numpy())
+    ens.launch_pf(traced=True)
+    ens.synchronize()
+    assert ens.ctx.last_variant() == "wg256x4s" and ens.ctx.last_traced()
     out = ens.out_dev.cpu().numpy()
+    assert np.array_equal(out[:, :4], production[:, :4])                      # every chain's gradient, bitwise
+    np.testing.assert_allclose(out[:, 4], production[:, 4], rtol=1e-12)       # log-lik: same terms, flushed per step when traced
     o = {k: t.cpu().numpy() for k, t in buf.items()}
     words = o["rec_u"].view(np.uint32)
     assert np.any(words != 0) and np.all(np.isfinite(o["rec_z"]))
@@ -165,3 +175,4 @@ def test_bench_launch_replayed_by_oracle_at_full_size():
     same = ens.ctx.run_batch(_problems(ens, d, 1, theta))
     for k in (c, c + 1, 0, ens.C - 1):
         assert np.array_equal(out[k, :3], same[k]["mean_stat"]), k
+        assert production[k, 4] == same[k]["loglik"], k
