@@ -175,12 +175,27 @@ __device__ __forceinline__ double u01_32(uint32_t a) { return ((double)a + 0.5) 
 // forms below need 17 / 20 / 17 and one LDS read, at <= 2 ulp -- well inside the parity
 // tolerance.  Tables are filled once per workgroup with ocml.  Explicit fma(): the file is
 // compiled with -ffp-contract=off.
-//   e2[j] = 2^(j/128)                                   j < 128
+//   e2[j] = 2^(j/TAB_E2)                                j < TAB_E2 (128; 32 in the device-generator units)
 //   lg[j] = {1/c_j, log c_j},  c_j = 1 + (j+0.5)/128    j < 128
 //   sc[j] = {sin, cos}(2 pi (j+0.5)/256)                j < 256
+// A/B (-DPFG_TAB_E2_FAST=32, device-generator units): a 32-entry 2^(j/32) table is exactly the 64 LDS banks, so a
+// ds_read_b64 with any 64 indices is conflict-free, at the price of one more polynomial term.  Measured (ms per bench
+// launch, 32 / 128 entries): SVM 47.45 / 46.97, GARCH windows 2.66 / 2.71, N = 4000 12.62 / 12.30, one wave 1.74 / 1.73,
+// N = 10000 6.82 / 6.77 -- the table reads are not where the LDS cycles go; 128 stays.
 // ------------------------------------------------------------------------------------
-constexpr int TAB_E2 = 128, TAB_LG = 128, TAB_SC = 0;     // no sin/cos table: see Math<double,true>::normal_pair
+constexpr int TAB_E2_ACC = 128, TAB_E2_FAST = 32;
+#ifdef PFG_FAST_ALGEBRA
+#ifndef PFG_TAB_E2_FAST
+#define PFG_TAB_E2_FAST 128
+#endif
+constexpr int TAB_E2 = PFG_TAB_E2_FAST;
+#else
+constexpr int TAB_E2 = TAB_E2_ACC;
+#endif
+constexpr int TAB_LG = 128, TAB_SC = 0;     // no sin/cos table: see Math<double,true>::normal_pair
 constexpr int TAB_DOUBLES_EXP = TAB_E2 + 2 * TAB_LG, TAB_DOUBLES_RNG = 2 * TAB_SC;   // exp+log always; sincos with the device RNG
+// table doubles of a kernel of the device-generator (fast) / REPLAY units, for host code compiled with other flags
+__host__ __device__ constexpr int tab_doubles_exp(bool fast) { return (fast ? 128 : TAB_E2_ACC) + 2 * TAB_LG; }
 
 struct TabF64 {
     const double *e2;
@@ -190,7 +205,7 @@ struct TabF64 {
 
 __device__ inline void tab_fill(double *mem, bool with_rng, int tid, int nthreads) {
     double *lg = mem + TAB_E2, *sc = lg + 2 * TAB_LG;
-    for (int j = tid; j < TAB_E2; j += nthreads) mem[j] = exp2((double)j * (1.0 / 128.0));
+    for (int j = tid; j < TAB_E2; j += nthreads) mem[j] = exp2((double)j * (1.0 / TAB_E2));
     for (int j = tid; j < TAB_LG; j += nthreads) {
         const double c = 1.0 + ((double)j + 0.5) * (1.0 / 128.0);
         lg[2 * j] = 1.0 / c; lg[2 * j + 1] = log(c);
@@ -209,12 +224,23 @@ __device__ inline void tab_fill(double *mem, bool with_rng, int tid, int nthread
 template <bool FINITE = false>
 __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e2) {
     if (!FINITE) x = fmax(x, -1000.0);
+#if defined(PFG_FAST_ALGEBRA) && PFG_TAB_E2_FAST == 32
+    // device-generator units: one-step reduction to |r| <= ln2/64 and a quartic for expm1 -- relative error
+    // r^5/120 < 1.3e-12, far below the Monte-Carlo noise these kernels carry; the REPLAY units keep the <= 2 ulp form
+    const double kd = rint(x * 46.16624130844683);                   // 32/ln2
+    const int k = (int)kd;
+    const double r = fma(kd, -0.021660849392498290, x);              // ln2/32
+    const double t = e2[k & (TAB_E2 - 1)];
+    double p = fma(r, 0.041666666666666664, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;
+    return ldexp(fma(t, p, t), k >> 5);
+#elif defined(PFG_FAST_ALGEBRA)
     const double kd = rint(x * 184.6649652337873);                  // 128/ln2
     const int k = (int)kd;
-#ifdef PFG_FAST_ALGEBRA
-    // device-generator units: one-step reduction and a cubic for expm1 -- relative error < 3e-12
-    // (|r| <= ln2/256: r^4/24 = 2e-12), far below the Monte-Carlo noise these kernels carry, and
-    // 4 instructions shorter; the REPLAY units keep the <= 2 ulp form below
+    // 128-entry table (-DPFG_TAB_E2_FAST=128, A/B): one-step reduction and a cubic for expm1 -- relative error < 3e-12
+    // (|r| <= ln2/256: r^4/24 = 2e-12)
     const double r = fma(kd, -0.0054152123481245725, x);             // ln2/128
     const double t = e2[k & (TAB_E2 - 1)];
     double p = fma(r, 0.16666666666666666, 0.5);
@@ -222,6 +248,8 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e
     p = p * r;
     return ldexp(fma(t, p, t), k >> 7);
 #else
+    const double kd = rint(x * 184.6649652337873);                  // 128/ln2
+    const int k = (int)kd;
     double r = fma(kd, -0.00541521234663378, x);                     // ln2/128, 32-bit head
     r = fma(kd, -1.4907929134926466e-12, r);                         //          tail
     const double t = e2[k & (TAB_E2 - 1)];

@@ -21,6 +21,17 @@ __host__ __device__ __forceinline__ constexpr int cdf_phys(int i) { return i + (
 // Everything except the 1024-thread single-buffer variant (which spends all LDS on particles).
 __host__ __device__ constexpr bool fast_layout(int NT, bool PP) { return PP || NT <= 512 || NT == 1024; }
 
+// State arrays x[NS][.], stats[H][.] of a FAST layout are NL + pad elements apart (pad = 8 bytes).  With a stride of
+// exactly NL = NT * PPT elements (a multiple of 512 bytes) the compiler fuses the gathers / stores of one particle's
+// entries in two arrays into ds_read2st64_b64 / ds_write2st64_b64, which the LDS serves at HALF the rate of two
+// ds_read_b64 (MI355X_MICROARCH.md, LDS table: 8 cycles per wave-instruction against 2 + 2; with the random
+// addresses of a gather about 24 against 14).  A stride that is no multiple of 512 bytes keeps them apart.
+// -DPFG_OPT_PADSTATE=0 restores the fused form (A/B).
+#ifndef PFG_OPT_PADSTATE
+#define PFG_OPT_PADSTATE 1
+#endif
+template <typename REAL> __host__ __device__ constexpr int state_pad() { return PFG_OPT_PADSTATE ? (int)(8 / sizeof(REAL)) : 0; }
+
 // workgroup barrier; a one-wave workgroup only needs its own LDS accesses kept in program order (the LDS
 // executes a wave's instructions in order): no s_barrier, no drain of the LDS queue
 template <int NW> __device__ __forceinline__ void block_sync() {
@@ -49,7 +60,8 @@ __host__ __device__ inline size_t reg_kernel_lds_bytes(int N) {
     size_t NC = FAST ? (size_t)NT * PPT + (size_t)NT * PPT / 32 : NL;   // padded 33/32 (see cdf_phys)
     // device generator (plain smoothers): 32-bit fixed-point CDF, see pf_reg_kernel
     constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
-    return (NC * (BLK ? 4 : 8) + 15) / 16 * 16 + (PP ? 2 : 1) * NL * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
+    const size_t NLS = NL + (FAST ? state_pad<REAL>() : 0);
+    return (NC * (BLK ? 4 : 8) + 15) / 16 * 16 + (PP ? 2 : 1) * NLS * (ModelDims<MODEL>::NS + ModelDims<MODEL>::H) * sizeof(REAL) +
            (size_t)RegLayout<NT, PPT>::RED * 8 + tab_bytes<REAL, RNG, FAST>() +
            (PARIS ? NL * 8 + NL * 4 + 3 * NL * 4 : 0);   // PaRIS: parents' log-weights, fallback queue,
                                                          // two wave-queue arrays, accepted parents
@@ -124,11 +136,16 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 #ifndef PFG_OPT_RCPW
 #define PFG_OPT_RCPW 1
 #endif
+#ifndef PFG_OPT_SEL32
+#define PFG_OPT_SEL32 1
+#endif
 #else
 #undef PFG_OPT_LAZYLL
 #undef PFG_OPT_RCPW
 #define PFG_OPT_LAZYLL 0
 #define PFG_OPT_RCPW 0
+#undef PFG_OPT_SEL32
+#define PFG_OPT_SEL32 0
 #endif
 // The device-generator SVM single-buffer workgroup needs 39.5 KB of LDS with the 32-bit CDF:
 // FOUR workgroups fit a CU if the kernel stays within 128 VGPRs (34 spilled registers; measured
@@ -191,7 +208,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     // LDS bytes per probe, no u32 -> f64 conversion of the uniform.
     uint32_t *cdfu = reinterpret_cast<uint32_t *>(smem);
     REAL *buf0 = reinterpret_cast<REAL *>(smem + ((size_t)NC * (BLK ? 4 : 8) + 15) / 16 * 16);
-    const size_t bufsz = (size_t)(NS + H) * NL;
+    // stride of the state arrays: NL + one 8-byte pad (FAST layouts) -- see state_pad()
+    const int NLS = NL + (FAST ? state_pad<REAL>() : 0);
+    const size_t bufsz = (size_t)(NS + H) * NLS;
     REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
     double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
     double *red_scan = red;                 // [PPT*NW]
@@ -283,9 +302,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     if (RNG == PFG_RNG_DEVICE && PFG_TR(P.trace_x) && P.rec_z0) P.rec_z0[i] = z;
                 }
 #pragma unroll
-                for (int d = 0; d < NS; ++d) cur[(size_t)d * NL + i] = x[d];
+                for (int d = 0; d < NS; ++d) cur[(size_t)d * NLS + i] = x[d];
 #pragma unroll
-                for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NL + i] = s[h];
+                for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NLS + i] = s[h];
                 if (PFG_TR(P.trace_x)) {
 #pragma unroll
                     for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int h = 0; h < H; ++h) {
                 double part = 0.0;
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) part += (double)cur[(size_t)(NS + h) * NL + own[k]] * cs[k];
+                for (int k = 0; k < PPT; ++k) part += (double)cur[(size_t)(NS + h) * NLS + own[k]] * cs[k];
                 part = wave_sum(part);
                 if (lane == 0) red_S[h * NW + wave] = part;
             }
@@ -526,6 +545,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             uint32_t ua[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) ua[k] = rng.next();
+#ifdef PFG_EXP_EVENWORDS
+            // knock-out (timing only, NOT a valid resampler): evenly spaced words in CDF order -- what sorted uniforms
+            // would do to the LDS bank conflicts of the search and the gathers, without their cost
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) ua[k] = (uint32_t)(((uint64_t)(tid * PPT + k) << 32) / (uint64_t)(NT * PPT)) + (ua[k] >> 12);
+#endif
             if (PFG_TR(P.trace_x) && P.rec_u) {           // test instrumentation: the words this launch searched with
 #pragma unroll
                 for (int k = 0; k < PPT; ++k)
@@ -545,8 +570,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 uint32_t cv[PPT];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) cv[k] = *(lds_u32 *)(uintptr_t)(off[k] + 4u * probe);
+                if constexpr (PFG_OPT_SEL32 && NT >= 512) {
+                // the advanced offset is formed while the probe is in flight; compare + select in the VOP2 forms
+                // (v_cmp_le_u32 vcc / v_cndmask_b32 with the implicit vcc).  The compiler's own lowering selects
+                // between 0 and the advance with the VOP3 form, which reads vcc as an SGPR operand: two wait states
+                // behind the compare, 22 s_nop per lane-timestep in this loop.  Measured (ms per bench launch, with /
+                // without): 512 x 2 GARCH 2.86 / 2.95, 1024 x 4 12.68 / 12.76, one wave 1.73 / 1.73, but 256 x 4 SVM
+                // 52.3 / 51.5 -- there the glued pairs keep the scheduler from weaving the generator's integer work
+                // into the search, which hides more than the wait states cost; so only for NT >= 512.
+                uint32_t cand[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) cand[k] = off[k] + 4u * adv;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    asm("v_cmp_le_u32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc"
+                        : "=v"(off[k]) : "v"(cv[k]), "v"(ua[k]), "v"(off[k]), "v"(cand[k]) : "vcc");
+                } else {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) off[k] += (cv[k] <= ua[k]) ? 4u * adv : 0u;
+                }
             }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -609,9 +651,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[k][d] = cur[(size_t)d * NL + anc[k]];
+                for (int d = 0; d < NS; ++d) xp[k][d] = cur[(size_t)d * NLS + anc[k]];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NL + anc[k]];
+                for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NLS + anc[k]];
             }
             PFG_PH(7)
             if (!PP) block_sync<NW>();                                          // barrier 4 (single buffer)
@@ -654,9 +696,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     if ((FAST && NT < 1024) || valid[k]) {
                         const int i = k * NT + tid;
 #pragma unroll
-                        for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + i] = xn[d];
+                        for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + i] = xn[d];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + i] = sp[k][h];
+                        for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + i] = sp[k][h];
                     }
                 }
             };
@@ -683,14 +725,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) {
                 REAL xp[NS], add[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NLS + anc[k]];
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
                 aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
 #pragma unroll
                 for (int h = 0; h < H; ++h) sacc[k][h] = (REAL)0;
                 if (valid[k]) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + k * NT + tid] = xn[k][d];
                 }
             }
             // wave-local work queues of pending children (this wave's NT*PPT/NW slots of two [NL]
@@ -730,7 +772,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     I = I < last ? I : last;
                     REAL xI[NS], xc[NS];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)d * NL + I]; xc[d] = nxt[(size_t)d * NL + child]; }
+                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)d * NLS + I]; xc[d] = nxt[(size_t)d * NLS + child]; }
                     const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
                     Iout = I;
                     return act && u2 <= thr;
@@ -789,7 +831,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         // the child's fallback uniform rides in its (still unused) statistic slot
                         const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
                                                                   : u01_32(rng.next());
-                        nxt[(size_t)NS * NL + i] = (REAL)um;
+                        nxt[(size_t)NS * NLS + i] = (REAL)um;
                     }
                 }
                 __syncthreads();
@@ -802,8 +844,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     const int ci = queue[e];
                     REAL xc[NS];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NL + ci];
-                    const double um = (double)nxt[(size_t)NS * NL + ci];
+                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NLS + ci];
+                    const double um = (double)nxt[(size_t)NS * NLS + ci];
                     if constexpr (RNG == PFG_RNG_DEVICE) {
                         // Device generator: any enumeration of the parents is a valid categorical
                         // sampler, so enumerate LANE-major (lane's parents lane, lane+64, ...): per-lane
@@ -821,7 +863,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                             const int qq = q < N ? q : last;
                             REAL xq[NS];
 #pragma unroll
-                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NLS + qq];
                             lq[mI] = (q < N && mI < nchunk) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc)
                                                             : (REAL)(-INFINITY);
                             mxf2 = fmaxf(mxf2, (float)lq[mI]);
@@ -861,7 +903,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         const int qq = q < N ? q : last;
                         REAL xq[NS];
 #pragma unroll
-                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NL + qq];
+                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NLS + qq];
                         l[mI] = (q < N) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc) : (REAL)(-INFINITY);
                         mxf = fmaxf(mxf, (float)l[mI]);
                         if (mI + 1 >= nchunk) break;
@@ -901,12 +943,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         P.trace_paris_J[((size_t)t * Nt + j) * N + k * NT + tid] = Jk;
                     REAL xJ[NS], aj[H];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NL + Jk];
+                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NLS + Jk];
                     additive_stat<MODEL, STAT, REAL>(c, xJ, xn[k], (REAL)y_t, aux[k], aj);
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
                         const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
-                        sacc[k][h] += cur[(size_t)(NS + h) * NL + Jk] + a;
+                        sacc[k][h] += cur[(size_t)(NS + h) * NLS + Jk] + a;
                     }
                 }
                 __syncthreads();                // queue / statistic-slot scratch free for the next j
@@ -916,7 +958,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
                 if (valid[k]) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = sacc[k][h] / (REAL)Nt;
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + k * NT + tid] = sacc[k][h] / (REAL)Nt;
                 }
             }
         };
@@ -932,12 +974,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) {
                 REAL xp[NS], add[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NL + anc[k]];
+                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NLS + anc[k]];
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
                 aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
                 if (valid[k]) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NL + k * NT + tid] = xn[k][d];
+                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + k * NT + tid] = xn[k][d];
                 }
             }
             REAL mx[PPT];
@@ -947,7 +989,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int j = 0; j < N; ++j) {
                 REAL xj[NS];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NLS + j];
                 const REAL lj = lwL[j];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
@@ -966,9 +1008,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int j = 0; j < N; ++j) {
                 REAL xj[NS], sj[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NL + j];
+                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NLS + j];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sj[h] = cur[(size_t)(NS + h) * NL + j];
+                for (int h = 0; h < H; ++h) sj[h] = cur[(size_t)(NS + h) * NLS + j];
                 const REAL lj = lwL[j];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
@@ -988,7 +1030,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
                 if (valid[k]) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NL + k * NT + tid] = num[k][h] / den[k];
+                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + k * NT + tid] = num[k][h] / den[k];
                 }
             }
         };
@@ -1018,12 +1060,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     const size_t row = (size_t)(t + 1) * N + i;
                     if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = anc[k];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NL + i];
+                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NLS + i];
                     P.trace_logw[row] = (double)lw[k];
                     if (P.trace_stats && !is_filter) {
 #pragma unroll
                         for (int h = 0; h < H; ++h)
-                            P.trace_stats[row * H + h] = (double)nxt[(size_t)(NS + h) * NL + i];
+                            P.trace_stats[row * H + h] = (double)nxt[(size_t)(NS + h) * NLS + i];
                     }
                 }
             }
@@ -1068,12 +1110,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             const int i = k * NT + tid;
             if (i < N) {
 #pragma unroll
-                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * NL + i];
+                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * NLS + i];
                 if (P.final_logw) P.final_logw[i] = (double)lw[k];
                 if (P.final_stats && !is_filter) {
 #pragma unroll
                     for (int h = 0; h < H; ++h)
-                        P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * NL + i];
+                        P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * NLS + i];
                 }
             }
         }

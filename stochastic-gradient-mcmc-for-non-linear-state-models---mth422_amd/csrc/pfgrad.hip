@@ -72,9 +72,10 @@ size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
     size_t NC = fast ? (size_t)v.NT * v.PPT + (size_t)v.NT * v.PPT / 32 : NL;
     size_t red = (size_t)v.PPT * (v.NT / 64) + (v.NT / 64) + (size_t)PFG_MAX_STAT * (v.NT / 64) + 8;
     size_t tab = (fast && dtype == PFG_F64)
-                     ? 8 * (size_t)(pfg::TAB_DOUBLES_EXP + (rng == PFG_RNG_DEVICE ? pfg::TAB_DOUBLES_RNG : 0)) : 0;
+                     ? 8 * (size_t)(pfg::tab_doubles_exp(rng == PFG_RNG_DEVICE) + (rng == PFG_RNG_DEVICE ? pfg::TAB_DOUBLES_RNG : 0)) : 0;
     const bool blk = fast && rng == PFG_RNG_DEVICE;        // 32-bit fixed-point CDF (pfg::pf_reg_kernel)
-    return (NC * (blk ? 4 : 8) + 15) / 16 * 16 + (v.pp ? 2 : 1) * NL * (state_dim(model) + stat_dim(model)) * rs + red * 8 + tab;
+    const size_t NLS = NL + (fast ? (size_t)(PFG_OPT_PADSTATE ? 8 / rs : 0) : 0);      // pfg::state_pad
+    return (NC * (blk ? 4 : 8) + 15) / 16 * 16 + (v.pp ? 2 : 1) * NLS * (state_dim(model) + stat_dim(model)) * rs + red * 8 + tab;
 }
 
 // index into kVariants, or -1 when no LDS-resident variant fits.  PFGRAD_VARIANT=<tag> forces a

@@ -23,9 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stochastic-gradient-mcmc-for-non-linear-state-models---mth422_amd"))
 from sgmcmc_ssm_amd import _build  # noqa: E402
 
-PHASES = {0: "A  block max (cvt, v_max DPP)", 1: "-  barrier 1", 2: "BC exp(lw-m), thread sums, wave scan", 3: "-  barrier 2",
-          4: "D  wave offsets, 1/W, log-lik park, CDF -> LDS", 5: "-  barrier 3", 6: "E  generator words + binary search",
-          7: "F  gather parents", 8: "-  barrier 4", 9: "GH normals, propose, weight, score, publish", -1: "(before the first marker)"}
+# PFG_PH(i) closes phase i (the stamps build adds the cycles since the previous marker to slot i): instructions that
+# follow marker i belong to phase i + 1, those behind marker 9 and before marker 0 to phase 0 of the next timestep
+PHASES = {0: "A  block max: cvt, thread max, v_max_f32 DPP", 1: "-  barrier 1 (wait + s_barrier)",
+          2: "BC max exchange, exp(lw-m), thread sums, wave scan", 3: "-  barrier 2",
+          4: "D  wave offsets, 1/W, log-lik park, y_t / weight, CDF -> LDS", 5: "-  barrier 3",
+          6: "E  generator words + binary search", 7: "F  gather parents", 8: "-  barrier 4",
+          9: "GH normals, propose, weight, score, publish"}
 
 F64_ARITH = ("v_add_f64", "v_mul_f64", "v_fma_f64", "v_fmac_f64")
 
@@ -153,7 +157,7 @@ def weights(blocks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--unit", default="svm_prior_device")
-    ap.add_argument("--kernel", default="pf_reg_kernel<0, 0, double, 256, 4, 1, false, 0>")
+    ap.add_argument("--kernel", default="pf_reg_kernel<0, 0, double, 256, 4, 1, false, 0, false>")
     ap.add_argument("--ppt", type=int, default=4)
     ap.add_argument("--flags", default="", help="extra compiler flags, space separated in ONE argument")
     ap.add_argument("--write", default=None)
@@ -164,12 +168,12 @@ def main():
     w, why = weights(blocks)
     per_phase = collections.defaultdict(lambda: collections.Counter())
     mnem = collections.defaultdict(lambda: collections.Counter())
-    phase = -1
+    phase = 0
     for b, wt in zip(blocks, w):
         for kind, text in b["items"]:
             if kind == "marker":
                 if text.startswith("PFG_PHASE"):
-                    phase = int(text.split()[1])
+                    phase = (int(text.split()[1]) + 1) % 10
                 continue
             m = text.split()[0]
             if m.startswith(";;"):
