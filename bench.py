@@ -48,6 +48,7 @@ import numpy as np  # noqa: E402
 T_SERIES, N_PART = 1000, 1000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
+N_CU = 256
 
 RNG_PRECISION = ("device generator: xoshiro128++ per lane keyed by Philox4x32-10(seed; lane, global chain id, step); "
                  "32-bit uniforms searched against a 32-bit fixed-point CDF (LDS-resident kernels) or an fp64 CDF "
@@ -229,15 +230,39 @@ def _load_json(name):
         return None
 
 
+def kernel_source_sha():
+    """sha256 over the sources the kernels are built from (csrc/*.hpp, csrc/*.hip, include/pfgrad.h, the build
+    flags in _build.py): the committed PMC counters (profiles/*.json) carry the hash they were taken at, and a
+    roofline computed from counters of OTHER sources is flagged `stale`."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hpp")) + glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")))
+    files += [os.path.join(ROOT, "include", "pfgrad.h"), os.path.join(PKG_DIR, "sgmcmc_ssm_amd", "_build.py")]
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_is_stale():
+    meta = _load_json("profile_meta.json") or {}
+    return meta.get("kernel_source_sha") != kernel_source_sha()
+
+
 def valu_roofline(key, chains, kern_ms, clock_ghz):
-    """VALU-issue roofline of an LDS-resident launch: per-class instruction counts (committed PMC
-    passes, profiles/valu_issue.json, scaled to `chains`) x calibrated issue cycles per class
-    (profiles/valu_calibration.json, measured with tools/calib/valu_calib at 4 waves per SIMD)."""
+    """VALU-issue roofline of an LDS-resident launch: per-class instruction counts (committed PMC passes,
+    profiles/valu_issue.json, scaled to `chains`) x issue cycles per class.  `frac` prices every instruction at its
+    ARCHITECTED issue cost (MI355X_MICROARCH.md: a SIMD-32 issues a 32-bit wave64 instruction in 2 cycles, fp64 at
+    half rate in 4, a transcendental in 8); `frac_vs_measured_streams` at what pure streams of one instruction
+    class reach on this GPU with four waves per SIMD (profiles/valu_calibration.json, first start to last end of a
+    launch: fp64 4.5, 32-bit 2.5-2.9, transcendental 8.4 cycles)."""
     rec = (_load_json("valu_issue.json") or {}).get(key)
     cal = _load_json("valu_calibration.json")
     if not rec or not cal or not (clock_ghz == clock_ghz):
         return None
-    cost = cal["cycles_per_wave_instruction_at_4_waves_per_simd"]
+    arch = cal["architected_cycles_per_wave_instruction"]
+    meas = cal["measured_cycles_per_wave_instruction_at_4_waves_per_simd"]
     scale = float(chains) / rec["chains"]
     cls = rec["classes"]
     f64 = (cls["ADD_F64"] + cls["MUL_F64"] + cls["FMA_F64"]) * scale
@@ -245,17 +270,33 @@ def valu_roofline(key, chains, kern_ms, clock_ghz):
     tr32 = cls["TRANS_F32"] * scale
     total = cls["VALU"] * scale
     other = total - f64 - tr64 - tr32
-    cycles = f64 * cost["f64"] + tr64 * cost["trans_f64"] + tr32 * cost["trans_f32"] + other * cost["b32"]
-    achieved = cycles / (kern_ms * 1e-3) / 1e9             # G issue-cycles per second actually delivered
+
+    def cycles(cost):
+        return f64 * cost["f64"] + tr64 * cost["trans_f64"] + tr32 * cost["trans_f32"] + other * cost["b32"]
     peak = N_SIMD * clock_ghz                               # G issue-cycles per second available
-    mixed = cal.get("mixed_stream_cycles_per_wave_instruction_at_4_waves_per_simd", {}).get("f64_share_0.22")
+    achieved = cycles(arch) / (kern_ms * 1e-3) / 1e9        # G issue-cycles per second delivered, architected costs
     return dict(achieved=achieved, peak=peak, frac=achieved / peak,
-                # against a stall-free stream of the kernel's own fp64 / 32-bit mix (alternating the two costs
-                # issue slots: 2.89 instead of 2.20 cycles per instruction): the estimate, `frac` is the lower bound
-                frac_mixed_stream=(total * mixed / (kern_ms * 1e-3) / 1e9 / peak) if mixed else None,
+                frac_vs_measured_streams=cycles(meas) / (kern_ms * 1e-3) / 1e9 / peak,
                 valu_instructions_per_launch=total, fp64_arith_instructions_per_launch=f64,
-                issue_cycle_model=cost, counters_from="profiles/valu_issue.json:" + key,
+                issue_cycle_model=arch, measured_stream_costs=meas, counters_from="profiles/valu_issue.json:" + key,
                 in_kernel_clock_ghz=clock_ghz)
+
+
+def lds_roofline(key, chains, kern_ms, clock_ghz):
+    """LDS-array utilisation of an LDS-resident launch: SQ_LDS_IDX_ACTIVE (every cycle the LDS array of a CU works,
+    bank-conflict cycles included; committed PMC pass, profiles/lds_activity.json, scaled to `chains`) against the
+    256 CUs x clock cycles the launch had."""
+    rec = (_load_json("lds_activity.json") or {}).get(key)
+    if not rec or not (clock_ghz == clock_ghz):
+        return None
+    scale = float(chains) / rec["chains"]
+    active = rec["SQ_LDS_IDX_ACTIVE"] * scale
+    conflict = rec["SQ_LDS_BANK_CONFLICT"] * scale
+    peak = N_CU * clock_ghz                                  # G LDS-array cycles per second available
+    achieved = active / (kern_ms * 1e-3) / 1e9
+    return dict(achieved=achieved, peak=peak, frac=achieved / peak, bank_conflict_share=conflict / active,
+                frac_conflict_free=(active - conflict) / (kern_ms * 1e-3) / 1e9 / peak,
+                lds_array_cycles_per_launch=active, counters_from="profiles/lds_activity.json:" + key)
 
 
 def replay_arithmetic_leg(w, dev_index, C=768, reps=3):
@@ -495,13 +536,25 @@ def main():
                             "resident while it fits); the algorithmic bytes are real memory-system traffic"}
         else:
             vr = valu_roofline(key, C, kern_ms, clock_ghz)
-            roof = {"bound": "valu", "achieved": vr["achieved"] if vr else None, "peak": vr["peak"] if vr else None,
-                    "unit": "G VALU issue-cycles/s", "frac": vr["frac"] if vr else None, "traffic": traffic,
-                    "kernel_ms": kern_ms, "in_kernel_clock_ghz": clock_ghz, "valu": vr, "hbm_model": hbm_model,
+            lr = lds_roofline(key, C, kern_ms, clock_ghz)
+            # the binding resource = the more utilised of the two pipes every timestep goes through
+            lds_binds = bool(lr and vr and lr["frac"] > vr["frac"])
+            top = lr if lds_binds else vr
+            roof = {"bound": "lds" if lds_binds else "valu", "achieved": top["achieved"] if top else None,
+                    "peak": top["peak"] if top else None,
+                    "unit": "G LDS-array cycles/s" if lds_binds else "G VALU issue-cycles/s", "frac": top["frac"] if top else None,
+                    "traffic": traffic, "kernel_ms": kern_ms, "in_kernel_clock_ghz": clock_ghz, "valu": vr, "lds": lr,
+                    "hbm_model": hbm_model,
                     "note": "particle state is LDS-resident: HBM bounds nothing here (traffic = measured bytes per launch, "
-                            "mostly register spills); the binding resource is VALU issue.  achieved = committed per-class "
-                            "instruction counts x calibrated issue cycles per class / live kernel time; peak = 1024 SIMDs x "
-                            "live in-kernel clock"}
+                            "register spills and descriptors).  Every timestep goes through two pipes, both reported: VALU issue "
+                            "(per-class instruction counts x architected issue cycles / (1024 SIMDs x clock)) and the LDS "
+                            "array (SQ_LDS_IDX_ACTIVE / (256 CUs x clock), bank-conflict cycles included); `bound` names the "
+                            "more utilised one.  Counters are committed PMC passes of this workload scaled by the chain "
+                            "count, time and clock are live"}
+        roof["stale"] = profile_is_stale()
+        if roof["stale"]:
+            roof["stale_note"] = ("the kernel sources differ from the ones profiles/*.json were measured on (profile_meta.json: "
+                                  "kernel_source_sha): instruction / LDS counters and traffic are those of an older kernel")
         line = {
             "metric": ("SGLD steps/sec (T=1000, N=1000 particles)" if args.config == "c2"
                        else "SGLD steps/sec ({0})".format(args.config)),

@@ -1,6 +1,7 @@
 """The committed profile files bench.py reads are consistent with the bench lines committed beside them:
-every config's roofline inputs exist under the key bench.py looks up, the VALU-issue fraction is a
-fraction, and the rocprofv3 kernel average agrees with the HIP-event time of the same run."""
+every config's roofline inputs exist under the key bench.py looks up, the VALU-issue and LDS-array fractions
+are fractions, the rocprofv3 kernel average agrees with the HIP-event time of the same run -- and the counters
+were taken on the kernel sources that are committed (a kernel edit without a re-profile fails here)."""
 import csv
 import json
 import os
@@ -15,12 +16,12 @@ PROF = os.path.join(ROOT, "profiles")
 
 @pytest.mark.parametrize("cfg", ["c1", "c2", "c3", "c4", "c5"])
 def test_profiles_match_bench_line(cfg):
-    line = json.load(open(os.path.join(PROF, "r02_{0}_bench.json".format(cfg))))
+    line = json.load(open(os.path.join(PROF, "r03_{0}_bench.json".format(cfg))))
     variant, chains, dtype = line["config"]["kernel_variant"], line["config"]["chains_per_gpu"], line["dtype"]
     assert chains == bench.CONFIGS[cfg][5]                    # profiled at the bench's default batch size
     key = "{0}_{1}_{2}".format(cfg, dtype, variant)
     kern_ms = line["roofline"]["kernel_ms"]
-    rows = list(csv.DictReader(open(os.path.join(PROF, "r02_{0}_kernel_stats.csv".format(cfg)))))
+    rows = list(csv.DictReader(open(os.path.join(PROF, "r03_{0}_kernel_stats.csv".format(cfg)))))
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     assert ("pf_big_kernel" if variant.startswith("big") else "pf_reg_kernel") in top["Name"]
     assert abs(float(top["AverageNs"]) * 1e-6 - kern_ms) < 0.05 * kern_ms      # rocprofv3 vs HIP events
@@ -33,7 +34,22 @@ def test_profiles_match_bench_line(cfg):
         return
     issue = json.load(open(os.path.join(PROF, "valu_issue.json")))
     assert key in issue and issue[key]["chains"] == chains
-    r = bench.valu_roofline(key, chains, kern_ms, line["roofline"]["in_kernel_clock_ghz"])
-    assert r is not None and 0.25 < r["frac"] < 1.0
-    assert line["roofline"]["bound"] == "valu" and abs(line["roofline"]["frac"] - r["frac"]) < 2e-3
+    lds = json.load(open(os.path.join(PROF, "lds_activity.json")))
+    assert key in lds and lds[key]["chains"] == chains
+    clock = line["roofline"]["in_kernel_clock_ghz"]
+    r = bench.valu_roofline(key, chains, kern_ms, clock)
+    l = bench.lds_roofline(key, chains, kern_ms, clock)
+    assert r is not None and 0.25 < r["frac"] < 1.0 and r["frac_vs_measured_streams"] > r["frac"]
+    assert l is not None and 0.25 < l["frac"] < 1.0 and 0.0 < l["bank_conflict_share"] < 0.7
+    top, name = (l, "lds") if l["frac"] > r["frac"] else (r, "valu")
+    assert line["roofline"]["bound"] == name and abs(line["roofline"]["frac"] - top["frac"]) < 2e-3
     assert traffic[key]["bytes_per_launch"] < 0.01 * line["roofline"]["hbm_model"]["algorithmic_bytes_per_launch"]
+
+
+def test_counters_belong_to_the_committed_kernel_sources():
+    """profiles/profile_meta.json carries the hash of the kernel sources the PMC passes ran on; bench.py flags a
+    roofline from other sources as stale.  Committed state: not stale."""
+    meta = json.load(open(os.path.join(PROF, "profile_meta.json")))
+    assert meta["kernel_source_sha"] == bench.kernel_source_sha(), \
+        "kernel sources changed since the last profile run: re-run tools/r03_profiles.sh + tools/make_profiles.py r03"
+    assert not bench.profile_is_stale()
