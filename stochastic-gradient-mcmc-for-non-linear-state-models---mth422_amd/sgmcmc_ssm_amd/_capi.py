@@ -319,6 +319,30 @@ class Context:
         gc_was_on = gc.isenabled() and B >= 256
         if gc_was_on:
             gc.disable()        # thousands of small containers below: generation-2 sweeps made this loop superlinear in B
+        try:
+            keep, outs = self._marshal(problems, ps, rs, want_final, want_trace, want_draws, want_elementwise)
+        finally:
+            if gc_was_on:
+                gc.enable()     # also when a problem is refused (ValueError): the collector must not stay off
+        t_call = time.perf_counter()
+        rc = self.lib.pfg_run_batch(self.handle, B, ps, rs)
+        self.last_call_seconds = time.perf_counter() - t_call      # the C call alone (pack, H2D, launch, D2H), without this marshalling
+        self._check(rc)
+        for b, o in enumerate(outs):
+            # the device record is STAT_DIM[model] wide; sufficient statistics use 3 columns
+            h = 3 if problems[b].get("stat", "score") != "score" else STAT_DIM[problems[b]["model"]]
+            o["mean_stat"] = np.array(rs[b].mean_stat[:h])
+            o["loglik"] = float(rs[b].loglik)
+            if problems[b].get("stat", "score") == "predictive":
+                o["predictive"] = np.array(rs[b].pred[:int(problems[b].get("num_steps_ahead", 0)) + 1])
+            for name in ("statistics", "all_statistics"):
+                if name in o:
+                    o[name] = o[name][..., :h]
+        del keep
+        return outs
+
+    def _marshal(self, problems, ps, rs, want_final, want_trace, want_draws, want_elementwise):
+        """Fill the ctypes problem / result arrays from the problem dicts; returns (arrays kept alive, output dicts)."""
         keep = []           # keep numpy buffers alive for the duration of the call
         outs = []
         for b, q in enumerate(problems):
@@ -410,24 +434,7 @@ class Context:
                     o["rec_ud"] = np.zeros((T, N))
                     r.rec_ud = _ptr(o["rec_ud"])
             outs.append(o)
-        if gc_was_on:
-            gc.enable()
-        t_call = time.perf_counter()
-        rc = self.lib.pfg_run_batch(self.handle, B, ps, rs)
-        self.last_call_seconds = time.perf_counter() - t_call      # the C call alone (pack, H2D, launch, D2H), without this marshalling
-        self._check(rc)
-        for b, o in enumerate(outs):
-            # the device record is STAT_DIM[model] wide; sufficient statistics use 3 columns
-            h = 3 if problems[b].get("stat", "score") != "score" else STAT_DIM[problems[b]["model"]]
-            o["mean_stat"] = np.array(rs[b].mean_stat[:h])
-            o["loglik"] = float(rs[b].loglik)
-            if problems[b].get("stat", "score") == "predictive":
-                o["predictive"] = np.array(rs[b].pred[:int(problems[b].get("num_steps_ahead", 0)) + 1])
-            for name in ("statistics", "all_statistics"):
-                if name in o:
-                    o[name] = o[name][..., :h]
-        del keep
-        return outs
+        return keep, outs
 
     def _run_batch_plain(self, problems):
         """Large batches that only ask for (mean_stat, loglik) from the device generator: the descriptors are

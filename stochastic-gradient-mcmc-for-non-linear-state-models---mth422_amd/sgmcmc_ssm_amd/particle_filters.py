@@ -50,6 +50,10 @@ _SPECULATE_MIN = 200000        # N*T from which the next stream is prefetched on
                                # 0.49 -> 0.79 ms per step at N*T = 24000, 8.5 -> 5.6 ms at 1e6)
 _stream_pool = {}
 _STREAM_POOL_MAX_BYTES = 512 << 20
+# the prefetch worker (speculation) and the caller's thread both take and return buffers: one lock for the pool and
+# the page-locked bookkeeping below
+import threading
+_pool_lock = threading.RLock()
 
 
 # Large stream buffers are page-locked once (pfg_host_register) and then live in the pool for the rest of the
@@ -62,19 +66,26 @@ _pinned_bytes = 0
 
 
 def _stream_buffers(N, T):
-    free = _stream_pool.get((N, T))
-    if free:
-        return free.pop()
     global _pinned_bytes
-    u, z = np.empty((T, N)), np.empty((T, N))
-    if u.nbytes >= _PIN_MIN_BYTES and _pinned_bytes + 2 * u.nbytes <= _PIN_MAX_BYTES:
-        u.fill(0.0); z.fill(0.0)           # touch the pages before locking them
-        if _capi.host_register(u):
-            if _capi.host_register(z):
+    with _pool_lock:
+        free = _stream_pool.get((N, T))
+        if free:
+            return free.pop()
+        u, z = np.empty((T, N)), np.empty((T, N))
+        want_pin = u.nbytes >= _PIN_MIN_BYTES and _pinned_bytes + 2 * u.nbytes <= _PIN_MAX_BYTES
+        if want_pin:
+            _pinned_bytes += 2 * u.nbytes      # reserved under the lock: two threads cannot both pass the cap
+    if want_pin:
+        u.fill(0.0); z.fill(0.0)               # touch the pages before locking them
+        ok = _capi.host_register(u)
+        if ok and not _capi.host_register(z):
+            _capi.host_unregister(u)
+            ok = False
+        with _pool_lock:
+            if ok:
                 _pinned.append((u, z))
-                _pinned_bytes += 2 * u.nbytes
             else:
-                _capi.host_unregister(u)
+                _pinned_bytes -= 2 * u.nbytes
     return u, z
 
 
@@ -82,14 +93,21 @@ def _is_pinned(bufs):
     return any(bufs[0] is p[0] for p in _pinned)
 
 
+def _recycle_bufs(bufs):
+    """Return one (u, z) pair to the pool: page-locked pairs always (registered pages must not go back to the
+    allocator), pageable ones while the pool is below its cap."""
+    if bufs is None:
+        return
+    with _pool_lock:
+        held = sum(len(v) * 2 * k[0] * k[1] * 8 for k, v in _stream_pool.items())
+        if held < _STREAM_POOL_MAX_BYTES or _is_pinned(bufs):
+            _stream_pool.setdefault(bufs[0].shape[::-1], []).append(bufs)
+
+
 def _recycle_streams(problems):
     """Return the u/z buffers of finished problems to the pool (the C call has copied them)."""
-    held = sum(len(v) * 2 * k[0] * k[1] * 8 for k, v in _stream_pool.items())
     for q in problems:
-        bufs = q.pop("_stream_bufs", None)
-        if bufs is not None and (held < _STREAM_POOL_MAX_BYTES or _is_pinned(bufs)):
-            _stream_pool.setdefault(bufs[0].shape[::-1], []).append(bufs)
-            held += 2 * bufs[0].nbytes
+        _recycle_bufs(q.pop("_stream_bufs", None))
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -147,14 +165,14 @@ class _Speculation(object):
             self.adopted += 1
             return z0, bufs
         self.discarded += 1
-        _stream_pool.setdefault((N, T) if (n, t) == (N, T) else (n, t), []).append(bufs)
+        _recycle_bufs(bufs)
         return None
 
     def cancel(self):
         if self.thread is not None:
             self.thread.join()
             if self.result is not None:
-                _stream_pool.setdefault((self.result[1], self.result[2]), []).append(self.result[4])
+                _recycle_bufs(self.result[4])
             self.thread, self.result = None, None
 
 
@@ -171,8 +189,7 @@ def draw_replay_streams(N, T, random_state=None, buffers=None):
     if rs is np.random:
         got = speculation.take(N, T)
         if got is not None:
-            if buffers is not None:
-                _stream_pool.setdefault((N, T), []).append(buffers)
+            _recycle_bufs(buffers)
             return got[0], got[1][0], got[1][1]
     u, z = buffers if buffers is not None else (np.empty((T, N)), np.empty((T, N)))
     if N * T >= _NATIVE_STREAM_MIN and (rs is np.random or isinstance(rs, np.random.RandomState)):

@@ -779,6 +779,39 @@ def make_theta_grid_fixtures():
     print("theta grid:", len(meta), "cases")
 
 
+
+def make_c_known_answer():
+    """tests/c_abi/known_answer.h: the traced reference case pf_trace.npz:c0 (SVM, prior kernel, poyiadjis_N, N = 32,
+    T = 16, window [3, 13) with weights) as C arrays -- inputs, the legacy-stream draws the reference's loop consumes
+    for np.random.seed(seed) (N normals, then per step N uniforms and N normals) and the reference's outputs -- so
+    that the plain-C consumer of the ABI checks numbers, not just return codes."""
+    z = np.load(os.path.join(HERE, "pf_trace.npz"))
+    meta = [m for m in json.loads(str(z["meta"])) if m["key"] == "c0"][0]
+    N, T = meta["N"], meta["T"]
+    rs = np.random.RandomState(meta["seed"])
+    z0 = rs.normal(size=N)
+    u, zz = np.empty((T, N)), np.empty((T, N))
+    for t in range(T):
+        u[t] = rs.random_sample(N)
+        zz[t] = rs.normal(size=N)
+
+    def arr(name, a):
+        a = np.asarray(a, dtype=float).reshape(-1)
+        body = ",\n    ".join(", ".join("%.17g" % v for v in a[i:i + 4]) for i in range(0, len(a), 4))
+        return "static const double %s[%d] = {\n    %s\n};\n" % (name, len(a), body)
+    out = ["/* Generated by tests/golden/make_golden.py (GOLDEN_ONLY=cheader) from tests/golden/pf_trace.npz:c0 -- data only:",
+           " * inputs, NumPy legacy-stream draws for np.random.seed(%d), and the REFERENCE's outputs for that case. */" % meta["seed"],
+           "#ifndef PFG_KNOWN_ANSWER_H", "#define PFG_KNOWN_ANSWER_H",
+           "#define KA_N %d" % N, "#define KA_T %d" % T, "#define KA_T1 %d" % meta["t1"], "#define KA_TL %d" % meta["tL"],
+           "static const double KA_PRIOR_MEAN = %.17g, KA_PRIOR_VAR = %.17g;" % (meta["prior_mean"], meta["prior_var"]),
+           "static const double KA_LOGLIK = %.17g;   /* reference all_loglikelihood_estimate[-1] */" % float(z["c0/all_loglikelihood_estimate"][-1]),
+           arr("KA_MEAN_STAT", z["c0/mean_statistic"]), arr("KA_THETA", z["c0/theta"]), arr("KA_Y", z["c0/y"]),
+           arr("KA_WEIGHTS", z["c0/weights"]), arr("KA_Z0", z0), arr("KA_U", u), arr("KA_Z", zz), "#endif", ""]
+    with open(os.path.join(os.path.dirname(HERE), "c_abi", "known_answer.h"), "w") as f:
+        f.write("\n".join(out))
+    print("c_abi/known_answer.h written: loglik", float(z["c0/all_loglikelihood_estimate"][-1]), "mean_stat", z["c0/mean_statistic"])
+
+
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY", "")
     if only in ("", "eurus"):
@@ -803,6 +836,8 @@ if __name__ == "__main__":
         make_predictive_fixtures()
     if only in ("", "theta_grid"):
         make_theta_grid_fixtures()
+    if only in ("", "cheader"):
+        make_c_known_answer()
     for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz", "theta_grid.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -276,3 +276,110 @@ def test_recorded_draws_are_standard(ctx, monkeypatch):
     # no serial structure between a child's word and its normal, or along the particle axis
     assert abs(np.corrcoef(u, z)[0, 1]) < 5 / np.sqrt(n)
     assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5 / np.sqrt(n)
+
+
+def _theta_grid():
+    """(model, tag, theta) of tests/golden/theta_grid.npz -- the grid the reference fixtures were generated on."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "theta_grid.npz"))
+    seen, out = set(), []
+    for m in json.loads(str(z["meta"])):
+        if (m["model"], m["tag"]) not in seen:
+            seen.add((m["model"], m["tag"]))
+            out.append((m["model"], m["tag"], z[m["key"] + "/theta"], z[m["key"] + "/y"] if not m["traced"] else None, m))
+    # observations: the N = 1000 window of the same (model, tag) (generated by the reference from that theta)
+    ys = {}
+    for m in json.loads(str(z["meta"])):
+        if not m["traced"]:
+            ys[(m["model"], m["tag"])] = (z[m["key"] + "/y"], m["prior_mean"], m["prior_var"])
+    return [(model, tag, theta) + ys[(model, tag)] for model, tag, theta, _, _ in out]
+
+
+GRID_VARIANTS = {
+    # model: (kernel, N, forced variant, (NT, PPT, cdf))
+    "svm": [("prior", 1000, "wg256x4s", (256, 4, "fixed32")), ("prior", 100, "wg64x2s", (64, 2, "fixed32")),
+            ("prior", 4000, "wg1024x4s", (1024, 4, "fixed32")), ("prior", 10000, "big16384", (16384, 1, "f64_uniform"))],
+    "lgssm": [("optimal", 100, "wg64x2s", (64, 2, "fixed32")), ("prior", 100, "wg64x2s", (64, 2, "fixed32")),
+              ("optimal", 1000, "wg256x4s", (256, 4, "fixed32")), ("optimal", 10000, "big16384", (16384, 1, "f64_uniform"))],
+    "garch": [("optimal", 1000, "wg512x2s", (512, 2, "fixed32")), ("prior", 1000, "wg512x2s", (512, 2, "fixed32")),
+              ("optimal", 100, "wg64x2s", (64, 2, "fixed32")), ("optimal", 10000, "big16384", (16384, 1, "f64_uniform"))],
+}
+
+
+@pytest.mark.parametrize("model,tag,theta,y,pm,pv", _theta_grid(), ids=lambda v: v if isinstance(v, str) else "")
+def test_theta_grid_device_kernels_replayed(ctx, monkeypatch, model, tag, theta, y, pm, pv):
+    """The timed instantiations over the reference's parameter grid (theta_grid.npz: C != 1, |A| = 0.9999, Cholesky
+    factors 0.1 / 10, phi = 0.999, lambduh 0.01 / 0.99): recorded draws replayed by the oracle, S = 16 / B = 4 windows
+    with importance weights, on wg256x4s / wg512x2s / wg64x2s / wg1024x4s / big16384."""
+    T, t1, tL = y.shape[0], 4, 20
+    weights = np.linspace(40.0, 61.0, tL - t1)
+    for kernel, N, variant, (NT, PPT, cdf) in GRID_VARIANTS[model]:
+        monkeypatch.setenv("PFGRAD_VARIANT", variant)
+        q = dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f64", rng="device", N=N, t1=t1, tL=tL,
+                 lambduh=1.0, prior_mean=pm, prior_var=pv, y=y, weights=weights, theta=theta, seed=4242 + N, stream=len(tag))
+        o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+        assert ctx.last_variant() == variant
+        words = o["rec_ud"] if cdf == "f64_uniform" else o["rec_u"]
+        with np.errstate(divide="ignore"):
+            ref = po.pf_window(model, theta, y, N, o["rec_z0"], None, o["rec_z"], kernel=kernel, pf="poyiadjis_N", lambduh=1.0,
+                               stat="score", t1=t1, tL=tL, weights=weights, prior_mean=pm, prior_var=pv, save_all=True,
+                               resampler=lambda t, logw: po.device_ancestors(logw, words[t], NT, PPT, cdf))
+        where = (model, tag, kernel, variant)
+        assert int(np.sum(o["all_ancestors"] != ref["all_ancestors"])) == 0, where
+        np.testing.assert_allclose(o["all_x_t"], ref["all_x_t"], rtol=RTOL, atol=ATOL, err_msg=str(where))
+        np.testing.assert_allclose(o["all_log_weights"], ref["all_log_weights"], rtol=RTOL, atol=ATOL, err_msg=str(where))
+        scale = max(1.0, np.abs(ref["all_statistics"]).max())
+        np.testing.assert_allclose(o["all_statistics"], ref["all_statistics"], rtol=RTOL, atol=1e-8 * scale, err_msg=str(where))
+        np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8 * scale, err_msg=str(where))
+        # log-likelihood: the reference's log(mean(exp(logw))) is not max-stabilised (buffered_smoother.py:124-126); with
+        # Rinv = 100 the log-weights sit near -1e3 and exp() lands in the denormal range (a few significant bits) or at
+        # zero, so the reference's OWN value is inexact there.  The kernel's is the max-stabilised form of the same sum:
+        # compare with that, computed from the oracle's log-weights, and with the reference form wherever it is exact.
+        lw = ref["all_log_weights"][1:]
+        mx = lw.max(axis=1)
+        steps = np.arange(T)
+        inside = (steps >= t1) & (steps < tL)
+        wt = np.where(inside, np.concatenate([np.zeros(t1), weights, np.zeros(T - tL)]), 0.0)
+        stable = float(np.sum(wt * (mx + np.log(np.mean(np.exp(lw - mx[:, None]), axis=1)))))
+        np.testing.assert_allclose(o["loglik"], stable, rtol=RTOL, atol=ATOL, err_msg=str(where))
+        if np.all(mx[inside] > -600.0):
+            np.testing.assert_allclose(o["loglik"], ref["loglikelihood_estimate"], rtol=RTOL, atol=ATOL, err_msg=str(where))
+        assert np.isfinite(o["loglik"])
+        plain = ctx.run_batch([dict(q)])[0]
+        assert np.array_equal(plain["mean_stat"], o["mean_stat"]), where
+
+
+@pytest.mark.parametrize("N,variant,NT", [(10000, "big16384", 16384), (4000, "big4096", 4096), (16384, "big16384", 16384)])
+def test_sorted_uniforms_of_the_large_n_kernel_are_uniform_order_statistics(ctx, monkeypatch, N, variant, NT):
+    """The large-N kernel resamples with SORTED uniforms built from exponential spacings and per-(chunk, wave)
+    offsets; the replay tests feed the recorded values back to the oracle, so a wrong offset or total would pass
+    them.  Here the recorded uniforms are tested for what they must be: per step the order statistics of N i.i.d.
+    U(0,1) -- pooled over steps a KS test against U(0,1), the normalised spacings (N+1)(U_(r) - U_(r-1)), incl. both
+    ends, against Exp(1), no correlation between neighbouring spacings, and mean U_(r) = r/(N+1) along the ranks."""
+    from scipy import stats
+    monkeypatch.setenv("PFGRAD_VARIANT", "big")            # the large-N kernel also where an LDS-resident variant would fit
+    T = 24
+    y = _series("svm", T, seed=N)
+    q = dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="device", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=0.0, prior_var=10.0, y=y, theta=THETA["svm"], seed=777 + N, stream=5)
+    o = ctx.run_batch([q], want_trace=True, want_draws=True)[0]
+    assert ctx.last_variant() == variant
+    child = np.arange(N)
+    rank = (child % NT) * 1 + child // NT                    # PPT = 1: child index = rank
+    ud = o["rec_ud"][:, np.argsort(rank)]                    # [T, N] in rank order
+    assert np.all(np.diff(ud, axis=1) >= 0.0) and np.all((ud > 0.0) & (ud < 1.0))
+    pooled = ud.reshape(-1)
+    assert stats.kstest(pooled, "uniform").pvalue > 1e-4
+    ends = np.concatenate([np.zeros((T, 1)), ud, np.ones((T, 1))], axis=1)
+    sp = np.diff(ends, axis=1) * (N + 1)                     # [T, N+1] normalised spacings
+    flat = sp.reshape(-1)
+    n = flat.size
+    assert stats.kstest(flat, "expon").pvalue > 1e-4
+    assert abs(flat.mean() - 1.0) < 1e-9                     # spacings of a step sum to one
+    assert abs(flat.var() - 1.0) < 6 * np.sqrt(8.0 / n)      # Var of Exp(1) = 1 (fourth central moment 9)
+    assert abs(np.corrcoef(sp[:, :-1].reshape(-1), sp[:, 1:].reshape(-1))[0, 1]) < 5 / np.sqrt(n)
+    # E[U_(r)] = r / (N + 1): the offsets between chunks and waves are right along the whole range
+    dev = ud.mean(axis=0) - np.arange(1, N + 1) / (N + 1.0)
+    sd = np.sqrt(np.arange(1, N + 1) * (N - np.arange(1, N + 1) + 1.0) / ((N + 1.0) ** 2 * (N + 2.0)) / T)
+    assert np.max(np.abs(dev) / sd) < 5.5

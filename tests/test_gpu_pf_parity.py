@@ -433,3 +433,45 @@ def test_one_wave_variant_replay_parity(ctx, monkeypatch, model, kernel):
         ref = r["statistics"] if q["smoother"] == "filter" else r["mean_statistic"]
         np.testing.assert_allclose(o["mean_stat"], ref, rtol=RTOL, atol=1e-8)
         assert abs(o["loglik"] - r["loglikelihood_estimate"]) <= ATOL + RTOL * abs(r["loglikelihood_estimate"])
+
+
+def test_theta_grid_replay_f64(ctx):
+    """Round 3: the reference over a GRID of parameters (tests/golden/theta_grid.npz: LGSSM C = 0.3 / 1.7 -- the
+    optimal kernel's weight "assumes C = 1", lgssm/kernels.py:117-120 --, |A| = 0.9999, Cholesky factors 0.1 / 10,
+    GARCH phi = 0.999, lambduh = 0.01 / 0.99).  REPLAY fp64, every traced step and the N = 1000 windows, rtol 1e-9.
+    Where the reference's own log-likelihood underflows to -inf (one Nemeth trace with log-weights of -3.6e5; it is
+    not max-stabilised, buffered_smoother.py:124-126) the kernel's must be finite (DESIGN deviation (i))."""
+    from conftest import Golden
+    g = Golden("theta_grid.npz")
+    by = {}
+    for m in g.meta:
+        by.setdefault((m["model"], m["kernel"], m["traced"]), []).append((m, _problem(m, g)))
+    n = 0
+    for (_, _, traced), items in by.items():
+        outs = ctx.run_batch([q for _, q in items], want_trace=traced, want_final=not traced)
+        for (m, _), o in zip(items, outs):
+            key = m["key"]
+            if traced:
+                np.testing.assert_allclose(o["all_x_t"], g.get(key, "all_x_t"), rtol=RTOL, atol=ATOL, err_msg=str(m))
+                np.testing.assert_allclose(o["all_log_weights"], g.get(key, "all_log_weights"), rtol=RTOL, atol=ATOL, err_msg=str(m))
+                ref_ll = g.get(key, "all_loglikelihood_estimate")
+                ok = np.isfinite(ref_ll)
+                np.testing.assert_allclose(o["all_loglikelihood_estimate"][ok], ref_ll[ok], rtol=RTOL, atol=ATOL, err_msg=str(m))
+                assert np.all(np.isfinite(o["all_loglikelihood_estimate"]))
+                if m["pf"] != "filter":
+                    ref = g.get(key, "all_statistics")
+                    scale = max(1.0, np.abs(ref).max())
+                    np.testing.assert_allclose(o["all_statistics"], ref, rtol=RTOL, atol=1e-9 * scale, err_msg=str(m))
+                    np.testing.assert_allclose(o["mean_stat"], g.get(key, "mean_statistic"), rtol=RTOL, atol=1e-9 * scale)
+                else:
+                    ref = g.get(key, "all_statistics")[-1]
+                    np.testing.assert_allclose(o["mean_stat"], ref, rtol=RTOL, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=str(m))
+            else:
+                ll = float(g.get(key, "loglikelihood_estimate"))
+                assert abs(o["loglik"] - ll) <= ATOL + RTOL * abs(ll), (m, o["loglik"], ll)
+                ref = g.get(key, "mean_statistic")
+                l2 = np.linalg.norm(o["mean_stat"] - ref)
+                assert l2 <= 1e-7 * max(1.0, np.linalg.norm(ref)), (m, o["mean_stat"], ref)
+                np.testing.assert_allclose(o["log_weights"], g.get(key, "log_weights"), rtol=RTOL, atol=ATOL, err_msg=str(m))
+            n += 1
+    assert n == len(g.meta) == 76

@@ -473,3 +473,47 @@ def test_unsupported_paths_raise():
         s.sample_sgld(epsilon=0.1, preconditioner=object())
     with pytest.raises(NotImplementedError):
         SVMSampler(n=2, m=1)
+
+
+def test_run_batch_restores_the_garbage_collector_on_a_refused_problem():
+    """run_batch switches the collector off while it marshals a large batch; a problem it refuses (here: window weights
+    shorter than the window) must not leave it off for the rest of the process."""
+    import gc
+    from sgmcmc_ssm_amd import _capi
+
+    class NoLibrary(_capi.Context):              # the marshalling needs no GPU: no handle is created
+        def __init__(self):
+            self.lib, self.handle = None, None
+    ctx = NoLibrary()
+    good = dict(model="svm", kernel="prior", N=8, y=np.zeros(4), theta=[0.9, 1.0, 1.0], rng="device", seed=1, stream=0)
+    bad = dict(good, t1=0, tL=4, weights=np.ones(2))
+    assert gc.isenabled()
+    with pytest.raises(ValueError, match="weights shorter"):
+        ctx.run_batch([good] * 300 + [bad], want_final=True)
+    assert gc.isenabled()
+
+
+def test_stream_pool_is_shared_safely_between_threads():
+    """The replay-stream buffer pool is used by the caller and by the prefetch worker thread: hammer it from several
+    threads (take, return) -- no IndexError from a racing pop, no buffer handed to two takers at once."""
+    import threading
+    from sgmcmc_ssm_amd import particle_filters as pfm
+    errors, seen = [], []
+
+    def work():
+        try:
+            for _ in range(300):
+                bufs = pfm._stream_buffers(16, 8)
+                seen.append(id(bufs[0]))
+                bufs[0][0, 0] = threading.get_ident()
+                assert bufs[0][0, 0] == threading.get_ident()
+                pfm._recycle_bufs(bufs)
+        except Exception as e:        # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(pfm._stream_pool.get((16, 8), [])) <= 6

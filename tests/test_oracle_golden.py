@@ -144,3 +144,29 @@ def test_poyiadjis_n2_oracle_bit_exact():
         if meta["traced"]:
             for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
                 assert np.array_equal(np.asarray(out[name], dtype=float), g.get(key, name)), (meta, name)
+
+
+def test_theta_grid_oracle_bit_exact():
+    """Round 3: the reference run over a GRID of parameters per (model, kernel) -- LGSSM C = 0.3 / 1.7 (the
+    optimal kernel's weight "assumes C = 1", models/lgssm/kernels.py:117-120: pinned as the reference computes it),
+    |A| = 0.9999, Cholesky factors 0.1 and 10, GARCH phi = 0.999 and lambduh = 0.01 / 0.99
+    (models/garch/kernels.py:136-180): traced tiny cases (every step) and N = 1000 windows, abs-err 0.0."""
+    from conftest import Golden
+    g = Golden("theta_grid.npz")
+    assert len(g.meta) == 76
+    tags = {(m["model"], m["tag"]) for m in g.meta}
+    assert len(tags) == 11
+    for meta in g.meta:
+        out = _run(meta, g, save_all=meta["traced"])
+        key = meta["key"]
+        if meta["traced"]:
+            for name in ("all_x_t", "all_log_weights", "all_statistics", "all_loglikelihood_estimate"):
+                ref = g.get(key, name)
+                got = np.asarray(out[name], dtype=float)
+                assert got.shape == ref.shape and np.array_equal(got, ref), (meta, name, np.max(np.abs(got - ref)))
+            if meta["pf"] != "filter":
+                assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic")), meta
+        else:
+            assert out["loglikelihood_estimate"] == float(g.get(key, "loglikelihood_estimate")), meta
+            assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic")), meta
+            assert np.array_equal(out["log_weights"], g.get(key, "log_weights")), meta
