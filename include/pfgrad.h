@@ -89,6 +89,8 @@ enum pfg_status {
 
 /* flags of pfg_problem / pfg_dev_problem */
 #define PFG_FLAG_GARCH_STATIONARY_PRIOR 1u /* prior_var = alpha/(1-beta-gamma) (garch/helper.py:324-327) */
+#define PFG_FLAG_PARIS_NO_ACCEPT_REJECT 2u /* paris_smoother(accept_reject=False), pf.py:226-236: every child draws its Ntilde
+                                            * parents from the exact backward categorical (REPLAY + paris_stream only) */
 
 /* One buffered PF window, host side (all pointers are HOST pointers, C-contiguous f64). */
 typedef struct pfg_problem {
@@ -123,6 +125,18 @@ typedef struct pfg_problem {
      * statistic matrix through HBM step by step.  NEMETH (any lambduh) and PARIS. */
     int32_t elementwise;
     const double *pred_z;
+    /* PaRIS in the REFERENCE's np.random order (REPLAY, N <= 1024): ONE sequential stream of uniforms, consumed as
+     * accept_reject_based_backward_sampling does (pf.py:260-341): per draw j and round, len(L) doubles for
+     * np.random.choice then len(L) for np.random.rand, the k-th pending child in index order taking the k-th of each;
+     * once <= paris_manual_threshold children are left (or after max_accept_reject rounds) one double per child for
+     * its exact draw.  Replaces the addressed pools paris_idx_u / acc_u / man_u (which must then be NULL).  The number
+     * of doubles consumed is data dependent: pfg_result.paris_consumed returns it (-1: the stream was too short, run
+     * again with a longer one).  The filter's own draws of a timestep (u, z) precede them in np.random's order, so a
+     * caller that reproduces np.random.seed() runs ONE timestep per call (warm start init_x / init_logw / init_stats),
+     * as sgmcmc_ssm_amd.particle_filters does. */
+    const double *paris_stream;
+    int64_t paris_stream_len;
+    int32_t paris_manual_threshold, reserved2;
     /* DEVICE rng: SGLD step the window belongs to, mixed into the generator key exactly as a resident chain's
      * device-side counter (*pfg_dev_problem.step_ctr) is: a window run through pfg_run_batch with
      * (seed, stream = global chain id, step) draws what that chain draws at that step through pfg_launch_device. */
@@ -157,6 +171,7 @@ typedef struct pfg_result {
     /* pfg_problem.elementwise: ew_mean [3 (tL-t1)] = average_statistic of the elementwise run (required);
      * ew_stats [N * 3 (tL-t1)] = its per-particle statistics, row-major (optional) */
     double *ew_mean, *ew_stats;
+    int64_t paris_consumed;  /* doubles of pfg_problem.paris_stream the window consumed; -1 = stream too short */
 } pfg_result;
 
 /* Device-side descriptor: one per workgroup, resident in HBM.  All pointers are DEVICE
@@ -192,6 +207,10 @@ typedef struct pfg_dev_problem {
     double *rec_ud;          /* [T*N] or NULL: see pfg_result.rec_ud */
     int32_t *trace_paris_J;  /* [T][Ntilde][N] or NULL (PARIS, with trace_x): the backward-sampled parent of
                                 every child and draw: the structure the elementwise statistics are carried through */
+    const double *paris_stream;      /* see pfg_problem.paris_stream */
+    int64_t paris_stream_len;
+    int64_t *paris_consumed;         /* [1] or NULL */
+    int32_t paris_manual_threshold, reserved4;
     uint64_t *stamps;        /* [PFG_STAMP_WORDS] or NULL (measurement): wave 0 of the workgroup writes
                                 s_memtime / s_memrealtime (100 MHz) at kernel start [0],[1] and end [2],[3]
                                 -> in-kernel shader clock = ([2]-[0]) / ([3]-[1]) * 100 MHz; [4..15]: per-phase

@@ -293,6 +293,9 @@ class NpDraws(object):
     def manual_uniform(self, t, j, i):
         return self.rng.random_sample(1)[0]
 
+    def child_uniforms(self, t, i, Ntilde):
+        return self.rng.random_sample(Ntilde)
+
 
 class PoolDraws(object):
     """Uniform draws addressed by (timestep, j, round, particle): what the device kernel reads.
@@ -431,7 +434,8 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
               lambduh=None, stat="score", t1=0, tL=None, weights=None,
               prior_mean=0.0, prior_var=1.0, save_all=False,
               Ntilde=2, max_accept_reject=None, manual_sample_threshold=None, paris_draws=None,
-              elementwise_statistic=False, num_steps_ahead=5, pred_normals=None, resampler=None):
+              elementwise_statistic=False, num_steps_ahead=5, pred_normals=None, resampler=None,
+              accept_reject=True):
     """One buffered PF window.
 
     Args:
@@ -542,8 +546,16 @@ def pf_window(model, theta, y, N, z0, u, z, kernel=None, pf="poyiadjis_N",
             continue
         if is_paris:
             # paris_smoother (pf.py:183-258): rewire Ntilde backward-sampled parents per child
-            J = paris_backward_indices(model, d, x, logw, x_next, Ntilde, paris_draws, t,
-                                       max_accept_reject, manual_sample_threshold)
+            if accept_reject:
+                J = paris_backward_indices(model, d, x, logw, x_next, Ntilde, paris_draws, t,
+                                           max_accept_reject, manual_sample_threshold)
+            else:
+                # paris_smoother(accept_reject=False), pf.py:226-236: the naive O(N^2) draw -- every child takes its
+                # Ntilde parents from the exact backward categorical, np.random.choice(size=Ntilde) per child
+                J = np.zeros((N, Ntilde), dtype=int)
+                for i in range(N):
+                    child_ll = prior_log_density(model, d, x, np.outer(np.ones(N), x_next[i]))
+                    J[i] = multinomial_ancestors(log_normalize(logw + child_ll), paris_draws.child_uniforms(t, i, Ntilde))
             flat = J.flatten()
             rew_parents = x[flat]
             xi_next = x_next[np.array([ii for ii in range(N) for _ in range(Ntilde)])]

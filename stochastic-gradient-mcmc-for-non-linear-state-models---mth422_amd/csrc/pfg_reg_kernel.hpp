@@ -319,6 +319,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     }
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
+    long long paris_cursor = 0;            // PaRIS in the reference's stream order: doubles of P.paris_stream consumed so far
+    bool paris_overflow = false;           // ... and whether the stream ran out (the host retries with a longer one)
     constexpr bool LAZYLL = PFG_OPT_LAZYLL && TAB && sizeof(REAL) == 8;
     double ll_W = 1.0, ll_w = 0.0;          // LAZYLL: lane t % 64 of wave 0 holds step t's (W, w, m)
     float ll_m = 0.0f;
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             int *const wq1 = paris_queue + 2 * NL + wave * (PPT * WAVE);
             int *const Jres = paris_queue + 3 * NL;
             const unsigned long long ltmask = (1ull << lane) - 1ull;
+            const bool ordered = RNG == PFG_RNG_REPLAY && P.paris_stream != nullptr;
             for (int j = 0; j < Nt; ++j) {
                 // ---- 2. accept-reject against the filter weights, up to R rounds per child ------
                 // Pending children sit compacted in a wave-local queue.  While more than half a
@@ -750,11 +753,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 // pools), so the long tail of rounds costs a handful of passes.
                 int *qa = wq0, *qb = wq1;
                 int cnt = 0;
+                if (!ordered) {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const unsigned long long mk = __ballot(valid[k]);
                     if (valid[k]) qa[cnt + __popcll(mk & ltmask)] = k * NT + tid;
                     cnt += __popcll(mk);
+                }
                 }
                 auto candidate = [&](int child, int round, bool act, int &Iout) {
                     double u1, u2;
@@ -823,6 +828,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 //         time over all parents -------------------------------------------------------
                 if (tid == 0) *qcount = 0;
                 __syncthreads();
+                if (ordered) {
+                    // ---- 2'. the REFERENCE's consumption order (pf.py:260-341): one sequential stream of uniforms.  Round
+                    // r of draw j takes len(L) doubles for np.random.choice and len(L) for np.random.rand, the k-th
+                    // pending child IN INDEX ORDER gets the k-th of each; once at most manual_sample_threshold children
+                    // are left (or after max_accept_reject rounds) each of them takes one double, in index order, for its
+                    // exact categorical draw.  The rank of a pending child = a workgroup-wide exclusive count of the
+                    // pending flags in particle-index order (slot-major: particle k * NT + tid).  accept_reject = False
+                    // (pf.py:226-236): no rounds, child i's draw j takes double i * Ntilde + j.
+                    const double *__restrict__ const strm = P.paris_stream;
+                    const long long cap = P.paris_stream_len;
+                    const bool noar = (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) != 0;
+                    const int mthr = P.paris_manual_threshold;
+                    int *const wcnt = paris_queue + NL;                 // [PPT][NW] pending children per (slot, wave)
+                    bool pend[PPT];
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) pend[k] = valid[k];
+                    int S = 0, rank[PPT];
+                    for (int round = 0;; ++round) {
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+                            const unsigned long long mk = __ballot(pend[k]);
+                            rank[k] = __popcll(mk & ltmask);
+                            if (lane == 0) wcnt[k * NW + wave] = __popcll(mk);
+                        }
+                        __syncthreads();
+                        S = 0;
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                if (w == wave) rank[k] += S;
+                                S += wcnt[k * NW + w];
+                            }
+                        }
+                        __syncthreads();                                // wcnt is rewritten by the next round
+                        if (S == 0 || noar || S <= mthr || round >= R || paris_overflow) break;
+                        if (paris_cursor + 2ll * S > cap) { paris_overflow = true; break; }
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+                            if (!pend[k]) continue;
+                            const double u1 = strm[paris_cursor + rank[k]], u2 = strm[paris_cursor + S + rank[k]];
+                            int I = 0;
+#pragma unroll
+                            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                                const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                                I += (cdf[I + probe] <= u1) ? step + (step >> 5) : 0;
+                            }
+                            I -= (I * 993) >> 15;
+                            I = I < last ? I : last;
+                            REAL xI[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NLS + I];
+                            const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn[k]));
+                            if (u2 <= thr) { Jres[k * NT + tid] = I; pend[k] = false; }
+                        }
+                        paris_cursor += 2ll * S;
+                    }
+                    // the children still pending, in index order: queue position = rank
+                    if (S > 0 && !noar && paris_cursor + S > cap) paris_overflow = true;
+                    if (S > 0 && noar && (long long)N * Nt > cap) paris_overflow = true;
+                    if (!paris_overflow) {
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+                            if (!pend[k]) continue;
+                            const int i = k * NT + tid;
+                            queue[rank[k]] = i;
+                            const double um = noar ? strm[(long long)i * Nt + j] : strm[paris_cursor + rank[k]];
+                            nxt[(size_t)NS * NLS + i] = (REAL)um;
+                        }
+                        if (tid == 0) *qcount = S;
+                        if (!noar) paris_cursor += S;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k)
+                            if (pend[k]) Jres[k * NT + tid] = 0;            // the host discards an overflowed window
+                    }
+                }
                 for (int e0 = 0; e0 < cnt; e0 += WAVE) {
                     const int e = e0 + lane;
                     if (e < cnt) {
@@ -1092,6 +1174,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         tie = red_max[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
+    }
+    if (PARIS && tid == 0 && P.paris_consumed) {
+        if (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) paris_cursor = (long long)N * P.Ntilde * T;
+        *P.paris_consumed = paris_overflow ? -1ll : paris_cursor;
     }
     if (tid == 0 && P.out) {
 #pragma unroll

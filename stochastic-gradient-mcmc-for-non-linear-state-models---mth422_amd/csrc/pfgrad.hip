@@ -623,8 +623,22 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         if (q.smoother == PFG_SMOOTHER_PARIS) {
             if (q.Ntilde < 1 || q.Ntilde > 64) return fail(ctx, PFG_ERR_INVALID, id + "Ntilde must be in [1, 64]");
             if (q.max_accept_reject < 0) return fail(ctx, PFG_ERR_INVALID, id + "max_accept_reject must be >= 0");
-            if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u))))
-                return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools");
+            if (q.paris_stream) {
+                if (rng != PFG_RNG_REPLAY) return fail(ctx, PFG_ERR_INVALID, id + "paris_stream is a REPLAY input");
+                if (q.paris_idx_u || q.paris_acc_u || q.paris_man_u)
+                    return fail(ctx, PFG_ERR_INVALID, id + "paris_stream replaces the addressed pools paris_idx_u / acc_u / man_u");
+                if (q.paris_stream_len < 0 || q.paris_manual_threshold < 0)
+                    return fail(ctx, PFG_ERR_INVALID, id + "paris_stream_len and paris_manual_threshold must be >= 0");
+                if (q.N > 1024)
+                    return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'paris' in the reference's stream order is built for N <= 1024");
+                if (q.elementwise) return fail(ctx, PFG_ERR_UNSUPPORTED, id + "paris_stream does not combine with elementwise statistics");
+            } else if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u)))) {
+                return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools or paris_stream");
+            }
+            if ((q.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) && !q.paris_stream)
+                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "PaRIS with accept_reject = False is built for the REPLAY stream order (paris_stream)");
+        } else if (q.paris_stream) {
+            return fail(ctx, PFG_ERR_INVALID, id + "paris_stream needs pf = 'paris'");
         }
         if (q.stat < PFG_STAT_SCORE || q.stat > PFG_STAT_PREDICTIVE) return fail(ctx, PFG_ERR_INVALID, id + "bad stat id");
         if ((q.stat == PFG_STAT_PREDICTIVE) != (ps[0].stat == PFG_STAT_PREDICTIVE))
@@ -677,6 +691,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             size_in(q.paris_idx_u, pool);
             size_in(q.paris_acc_u, pool);
             size_in(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
+            size_in(q.paris_stream, (size_t)q.paris_stream_len);
+            if (q.paris_stream) n_out += 1;                                   // the consumed count
         }
         if (q.stat == PFG_STAT_PREDICTIVE && rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM)
             size_in(q.pred_z, (size_t)q.T * (q.num_steps_ahead + 1) * q.N);
@@ -837,6 +853,13 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                 d.paris_idx_u = put(q.paris_idx_u, pool);
                 d.paris_acc_u = put(q.paris_acc_u, pool);
                 d.paris_man_u = put(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
+                if (q.paris_stream) {
+                    d.paris_stream = put(q.paris_stream, (size_t)q.paris_stream_len);
+                    if (!d.paris_stream) d.paris_stream = din;        // an empty stream is still "stream order" (non-NULL)
+                    d.paris_stream_len = q.paris_stream_len;
+                    d.paris_manual_threshold = q.paris_manual_threshold;
+                    d.paris_consumed = reinterpret_cast<int64_t *>(take(true, 1));
+                }
             }
         }
         if (predictive) {
@@ -939,6 +962,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         fetch(r.rec_z, d.rec_z, (size_t)q.T * q.N);
         fetch(r.rec_z0, d.rec_z0, q.N);
         fetch(r.rec_ud, d.rec_ud, (size_t)q.T * q.N);
+        r.paris_consumed = 0;
+        if (d.paris_consumed) std::memcpy(&r.paris_consumed, host_of(reinterpret_cast<const double *>(d.paris_consumed)), 8);
         if (q.elementwise) {
             fetch(r.ew_mean, ew[b].mean, ew[b].Wd);
             fetch(r.ew_stats, ew[b].stats, (size_t)q.N * ew[b].Wd);

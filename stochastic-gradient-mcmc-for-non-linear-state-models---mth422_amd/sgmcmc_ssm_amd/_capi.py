@@ -19,6 +19,7 @@ STAT = {"score": 0, "suff": 1, "none": 2, "predictive": 3}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
+FLAG_PARIS_NO_ACCEPT_REJECT = 2
 MAX_STAT, MAX_THETA, OUT_DOUBLES, MAX_PRED, STAMP_WORDS = 4, 4, 8, 16, 16
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
@@ -44,6 +45,8 @@ class Problem(C.Structure):
         ("paris_idx_u", _dp), ("paris_acc_u", _dp), ("paris_man_u", _dp),
         ("num_steps_ahead", C.c_int32), ("elementwise", C.c_int32),
         ("pred_z", _dp),
+        ("paris_stream", _dp), ("paris_stream_len", C.c_int64),
+        ("paris_manual_threshold", C.c_int32), ("reserved2", C.c_int32),
         ("step", C.c_uint64),
     ]
 
@@ -59,6 +62,7 @@ class Result(C.Structure):
         ("rec_u", C.POINTER(C.c_uint32)), ("rec_z", _dp), ("rec_z0", _dp),
         ("rec_ud", _dp),
         ("ew_mean", _dp), ("ew_stats", _dp),
+        ("paris_consumed", C.c_int64),
     ]
 
 
@@ -73,14 +77,17 @@ PROBLEM_DTYPE = np.dtype([
     ("init_x", "u8"), ("init_logw", "u8"), ("init_stats", "u8"),
     ("Ntilde", "i4"), ("max_accept_reject", "i4"),
     ("paris_idx_u", "u8"), ("paris_acc_u", "u8"), ("paris_man_u", "u8"),
-    ("num_steps_ahead", "i4"), ("elementwise", "i4"), ("pred_z", "u8"), ("step", "u8")], align=True)
+    ("num_steps_ahead", "i4"), ("elementwise", "i4"), ("pred_z", "u8"),
+    ("paris_stream", "u8"), ("paris_stream_len", "i8"), ("paris_manual_threshold", "i4"), ("reserved2", "i4"),
+    ("step", "u8")], align=True)
 RESULT_DTYPE = np.dtype([
     ("mean_stat", "f8", (MAX_STAT,)), ("loglik", "f8"),
     ("x_T", "u8"), ("logw_T", "u8"), ("stats_T", "u8"),
     ("trace_x", "u8"), ("trace_logw", "u8"), ("trace_stats", "u8"), ("trace_ll", "u8"),
     ("status", "i4"), ("reserved", "i4"), ("trace_anc", "u8"),
     ("pred", "f8", (MAX_PRED,)),
-    ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"), ("rec_ud", "u8"), ("ew_mean", "u8"), ("ew_stats", "u8")], align=True)
+    ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"), ("rec_ud", "u8"), ("ew_mean", "u8"), ("ew_stats", "u8"),
+    ("paris_consumed", "i8")], align=True)
 assert PROBLEM_DTYPE.itemsize == C.sizeof(Problem) and RESULT_DTYPE.itemsize == C.sizeof(Result)
 assert all(PROBLEM_DTYPE.fields[n][1] == getattr(Problem, n).offset for n, _ in Problem._fields_)
 assert all(RESULT_DTYPE.fields[n][1] == getattr(Result, n).offset for n, _ in Result._fields_)
@@ -114,6 +121,8 @@ DEV_PROBLEM_DTYPE = np.dtype([
     ("num_steps_ahead", "i4"), ("reserved3", "i4"),
     ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"),
     ("rec_ud", "u8"), ("trace_paris_J", "u8"),
+    ("paris_stream", "u8"), ("paris_stream_len", "i8"), ("paris_consumed", "u8"),
+    ("paris_manual_threshold", "i4"), ("reserved4", "i4"),
     ("stamps", "u8"),
 ], align=True)
 
@@ -253,7 +262,7 @@ def host_unregister(a):
 
 
 _OPTIONAL_ARRAYS = ("weights", "z0", "u", "z", "init_x", "init_logw", "init_stats",
-                    "paris_idx_u", "paris_acc_u", "paris_man_u", "pred_z")
+                    "paris_idx_u", "paris_acc_u", "paris_man_u", "pred_z", "paris_stream")
 _NO_ARRAYS = dict.fromkeys(("y", "theta") + _OPTIONAL_ARRAYS)
 
 
@@ -335,6 +344,8 @@ class Context:
             o["loglik"] = float(rs[b].loglik)
             if problems[b].get("stat", "score") == "predictive":
                 o["predictive"] = np.array(rs[b].pred[:int(problems[b].get("num_steps_ahead", 0)) + 1])
+            if problems[b].get("paris_stream", None) is not None:
+                o["paris_consumed"] = int(rs[b].paris_consumed)
             for name in ("statistics", "all_statistics"):
                 if name in o:
                     o[name] = o[name][..., :h]
@@ -387,7 +398,10 @@ class Context:
             keep.append(arrs)
             o = {}
             r = rs[b]
-            if p.smoother == SMOOTHER["paris"] and p.rng == RNG["replay"]:
+            if arrs["paris_stream"] is not None:
+                p.paris_stream_len = arrs["paris_stream"].shape[0]
+                p.paris_manual_threshold = int(q.get("paris_manual_threshold", 0))
+            elif p.smoother == SMOOTHER["paris"] and p.rng == RNG["replay"]:
                 pool = T * p.Ntilde * p.max_accept_reject * N
                 for name, need in (("paris_idx_u", pool), ("paris_acc_u", pool), ("paris_man_u", T * p.Ntilde * N)):
                     if need and (arrs[name] is None or arrs[name].shape[0] != need):
@@ -441,7 +455,7 @@ class Context:
         filled column by column into a structured array (a ctypes attribute store per field and problem cost
         19 us per problem, four times the kernel's share of a 12288-window launch).  None = not eligible."""
         B = len(problems)
-        blocked = ("z0", "u", "z", "init_x", "init_logw", "init_stats", "paris_idx_u", "paris_acc_u", "paris_man_u", "pred_z")
+        blocked = ("z0", "u", "z", "init_x", "init_logw", "init_stats", "paris_idx_u", "paris_acc_u", "paris_man_u", "pred_z", "paris_stream")
         for q in problems:
             if RNG[q.get("rng", "replay")] != RNG["device"] or q.get("stat", "score") == "predictive":
                 return None

@@ -251,18 +251,24 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
     T = y.shape[0]
     paris_kw = {}
     if smoother == "paris":
-        # PaRIS (pf.py:183-341).  Its backward-sampling draws are data-dependent in number, so the
-        # reference's np.random order cannot be replayed from pre-drawn streams: unless explicit
-        # uniform pools are passed (tests), the device generator is used, keyed from np.random
-        # (reproducible under np.random.seed; statistically equivalent to the reference).
-        # `manual_sample_threshold` (an early exit to the exact fallback) is a host-speed knob of
-        # the reference and is not needed here: every child runs accept-reject for
-        # max_accept_reject rounds, then the same exact categorical fallback.
-        if not kwargs.pop("accept_reject", True):
-            raise NotImplementedError("PaRIS with accept_reject=False (O(N^2)) is not on the HIP backend")
-        kwargs.pop("manual_sample_threshold", None)
+        # PaRIS (pf.py:183-341).  Its backward-sampling draws are data dependent in number and interleave with the
+        # filter's draws in np.random's order.  rng='replay' with N <= 1024 reproduces that order exactly: the
+        # window runs here and now, one kernel launch per timestep (_paris_replay_window), so that np.random.seed(s)
+        # gives the reference's numbers and leaves the generator where the reference leaves it.  Explicit uniform
+        # pools (tests) use the addressed form; larger N and rng='device' use the device generator, keyed from
+        # np.random (reproducible under np.random.seed, statistically equivalent to the reference).
+        accept_reject = bool(kwargs.pop("accept_reject", True))
+        mst = kwargs.pop("manual_sample_threshold", None)
         mar = kwargs.pop("max_accept_reject", None)
         paris_kw["Ntilde"] = int(kwargs.pop("Ntilde", 2))
+        pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
+        if rng == "replay" and pools[2] is None and int(N) <= 1024 and stat in ("score", "suff") and dtype == "f64":
+            q = dict(model=model, kernel=kernel, smoother="paris", stat=stat, dtype=dtype, rng="replay", N=int(N),
+                     t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=1.0, Ntilde=paris_kw["Ntilde"],
+                     prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
+                     prior_var=float(np.asarray(prior_var).reshape(-1)[0]), y=y, weights=weights, theta=theta, flags=flags)
+            q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state)
+            return q
         # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
         # left and draws those exactly (its own cap is 100 log10(N/10) rounds); a fixed number of
         # rounds followed by the exact draw is the device equivalent.  The exact draw costs O(N)
@@ -272,7 +278,10 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         # (exact draw = 10000 parents): 2196 / 659 / 400 us with 16 / 64 / 256 rounds.
         default_rounds = 64 if int(N) <= 1024 else 256
         paris_kw["max_accept_reject"] = default_rounds if mar is None else max(0, int(mar))
-        pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
+        if not accept_reject:
+            # paris_smoother(accept_reject=False), pf.py:226-236: every child draws its parents from the exact backward
+            # categorical -- no accept-reject rounds, the exact draw for every child
+            paris_kw["max_accept_reject"] = 0
         if rng == "replay" and pools[2] is None:
             rng = "device"
         elif rng == "replay":
@@ -308,6 +317,71 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
     return q
 
 
+_paris_block_hint = {}          # (N, Ntilde) -> doubles a timestep's backward sampling consumed last time (stream block size)
+
+
+def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None):
+    """One PaRIS window consuming the legacy generator EXACTLY as the reference does (paris_smoother +
+    accept_reject_based_backward_sampling, pf.py:183-341): N normals for x0, then per timestep N uniforms
+    (np.random.choice), N normals (Kernel.rv) and the data-dependent run of uniforms of the backward sampling.
+    One kernel launch per timestep, warm-started from the previous step's particles: the host draws the filter's
+    u / z, hands the kernel a block of further uniforms (pfg_problem.paris_stream), and afterwards rewinds the
+    generator to the end of the filter's draws and advances it by exactly what the kernel reports as consumed.
+    Returns the dict run_batch would (mean_stat, loglik, x_t, log_weights, statistics, all_* traces)."""
+    ctx = _capi.default_context()
+    rs = np.random if random_state is None else random_state
+    N, Nt, y = q["N"], q["Ntilde"], q["y"]
+    T, t1, tL = y.shape[0], q["t1"], min(q["tL"], y.shape[0])
+    ns, h = _capi.STATE_DIM[q["model"]], (_capi.STAT_DIM[q["model"]] if q["stat"] == "score" else 3)
+    # pf.py:282-285 (range() of a negative count is empty, a negative threshold is never reached)
+    mar = int(100 * np.log10(N / 10)) if max_accept_reject is None else int(max_accept_reject)
+    mst = int(10 * np.log10(N / 10)) if manual_sample_threshold is None else int(manual_sample_threshold)
+    mar, mst = max(mar, 0), max(mst, 0)
+    base = dict(model=q["model"], kernel=q["kernel"], stat=q["stat"], dtype="f64", rng="replay", N=N, lambduh=1.0,
+                theta=q["theta"], prior_mean=q["prior_mean"], prior_var=q["prior_var"])
+    flags = int(q.get("flags", 0))
+    # x0 (LatentGaussianKernel.sample_x0, kernels.py:83-100): a T = 0 window returns the initial particle system
+    z0 = rs.normal(size=N)
+    o = ctx.run_batch([dict(base, smoother="nemeth", flags=flags, y=np.zeros(0), t1=0, tL=0, z0=z0, u=np.zeros(0), z=np.zeros(0))],
+                      want_final=True)[0]
+    x, logw, stats = o["x_t"], o["log_weights"], np.zeros((N, _capi.STAT_DIM[q["model"]]))
+    all_x, all_lw, all_st, all_ll = [x.copy()], [logw.copy()], [stats[:, :h].copy()], [0.0]
+    ll, mean_stat = 0.0, np.zeros(h)
+    pflags = flags | (0 if accept_reject else _capi.FLAG_PARIS_NO_ACCEPT_REJECT)
+    for t in range(T):
+        u = rs.random_sample(N)
+        z = rs.normal(size=N)
+        inside = t1 <= t < tL
+        w = None
+        if inside and q.get("weights", None) is not None:
+            w = np.array([float(np.asarray(q["weights"]).reshape(-1)[t - t1])])
+        M = N * Nt if not accept_reject else max(_paris_block_hint.get((N, Nt), 0) * 2, 8 * N * Nt) + 64
+        after_filter = rs.get_state()
+        while True:
+            block = rs.random_sample(M)
+            step = dict(base, smoother="paris", flags=pflags, y=y[t:t + 1], t1=0, tL=1 if inside else 0, weights=w,
+                        init_x=x, init_logw=logw, init_stats=stats, u=u.reshape(1, N), z=z.reshape(1, N),
+                        Ntilde=Nt, max_accept_reject=mar, paris_stream=block, paris_manual_threshold=mst)
+            o = ctx.run_batch([step], want_final=True)[0]
+            used = o["paris_consumed"]
+            rs.set_state(after_filter)
+            if used >= 0:
+                break
+            M *= 4                      # the block ran out: the same step again with a longer one
+        if used > 0:
+            rs.random_sample(used)      # the generator now stands where the reference's stands
+        _paris_block_hint[(N, Nt)] = max(int(used), 1)
+        x, logw = o["x_t"], o["log_weights"]
+        stats = np.zeros((N, _capi.STAT_DIM[q["model"]]))
+        stats[:, :o["statistics"].shape[1]] = o["statistics"]
+        ll += o["loglik"]
+        mean_stat = o["mean_stat"]
+        all_x.append(x.copy()); all_lw.append(logw.copy()); all_st.append(stats[:, :h].copy()); all_ll.append(ll)
+    return dict(mean_stat=np.asarray(mean_stat)[:h], loglik=ll, x_t=x, log_weights=logw, statistics=stats[:, :h],
+                all_x_t=np.array(all_x), all_log_weights=np.array(all_lw), all_statistics=np.array(all_st),
+                all_loglikelihood_estimate=np.array(all_ll))
+
+
 def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
                         save_all=False, want_final=True, **kwargs):
     """Run one buffered PF window on the GPU.
@@ -317,6 +391,8 @@ def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
     with save_all=True, the all_* traces of buffered_smoother.py:128-142."""
     q = make_problem(model, kernel, pf, observations, theta, N, **kwargs)
     ctx = ctx or _capi.default_context()
+    if "_result" in q:                  # PaRIS in np.random's order: the window ran while its draws were due
+        return _to_reference_dict(q["_result"], q)
     o = ctx.run_batch([q], want_final=want_final or save_all, want_trace=save_all)[0]
     out = _to_reference_dict(o, q)
     _recycle_streams([q])
@@ -344,8 +420,9 @@ def _to_reference_dict(o, q):
 def run_windows(problems, ctx=None, want_final=False):
     """Many independent windows (same model/kernel/dtype/rng) in ONE launch, one workgroup each."""
     ctx = ctx or _capi.default_context()
-    outs = ctx.run_batch(problems, want_final=want_final)
-    res = [_to_reference_dict(o, q) for o, q in zip(outs, problems)]
+    todo = [q for q in problems if "_result" not in q]
+    outs = iter(ctx.run_batch(todo, want_final=want_final) if todo else [])
+    res = [_to_reference_dict(q["_result"] if "_result" in q else next(outs), q) for q in problems]
     _recycle_streams(problems)
     return res
 

@@ -409,6 +409,82 @@ def make_paris_fixtures():
     np.savez_compressed(os.path.join(HERE, "paris.npz"), **out)
 
 
+
+def make_paris_seed_fixtures():
+    """PaRIS through the reference's PUBLIC entry points, seed for seed (round 3): Helper.pf_gradient_estimate /
+    pf_loglikelihood_estimate(pf='paris') and Sampler.sample_sgld(pf='paris') after np.random.seed(s), at the demos'
+    particle count (N = 1000, exchange_rate_demo_gbp.py:66), incl. accept_reject=False (pf.py:226-236) and non-default
+    thresholds -- plus the NEXT np.random draw after each call, which pins how far the call advanced the generator."""
+    out, meta = {}, []
+    helpers = {"svm": SVMHelper, "garch": GARCHHelper, "lgssm": LGSSMHelper}
+    cases = [("svm", None, 1000, 24, 4, 20, dict()),
+             ("svm", None, 300, 12, 0, 12, dict(Ntilde=3)),
+             ("svm", None, 200, 10, 2, 8, dict(accept_reject=False)),
+             ("svm", None, 1000, 8, 2, 8, dict(max_accept_reject=4, manual_sample_threshold=50)),
+             ("garch", None, 1000, 24, 4, 20, dict()),
+             ("garch", "prior", 300, 12, 2, 10, dict(Ntilde=1)),
+             ("lgssm", None, 1000, 24, 4, 20, dict()),
+             ("lgssm", "prior", 257, 10, 0, 10, dict(accept_reject=False, Ntilde=3)),
+             ("lgssm", None, 64, 10, 2, 9, dict(manual_sample_threshold=0))]
+    for ci, (model, kernel, N, T, t1, tL, kw) in enumerate(cases):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(900 + ci)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        fm = data["initial_message"] if model != "garch" else None
+        helper = helpers[model](forward_message=fm, **p.dim) if model != "garch" else helpers[model](**p.dim)
+        weights = 1.0 + 0.25 * np.arange(tL - t1)
+        seed = 8100 + ci
+        np.random.seed(seed)
+        g = helper.pf_gradient_estimate(observations=y, parameters=p, subsequence_start=t1, subsequence_end=tL, weights=weights,
+                                        pf="paris", N=N, kernel=kernel, **kw)
+        nxt = np.random.random_sample()
+        np.random.seed(seed)
+        ll = helper.pf_loglikelihood_estimate(observations=y, parameters=p, subsequence_start=t1, subsequence_end=tL,
+                                              weights=weights, pf="paris", N=N, kernel=kernel, **kw)
+        nxt_ll = np.random.random_sample()
+        key = "s{0}".format(len(meta))
+        meta.append(dict(key=key, model=model, kernel=kernel, N=N, T=T, t1=t1, tL=tL, seed=seed, kwargs=kw, kind="helper",
+                         has_forward_message=fm is not None))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        out[key + "/weights"] = weights
+        out[key + "/grad"] = as_vec(model, g)
+        out[key + "/next_draw"] = np.float64(nxt)
+        out[key + "/loglik"] = np.float64(ll)
+        out[key + "/next_draw_loglik"] = np.float64(nxt_ll)
+        if fm is not None:
+            out[key + "/fm_precision"] = np.asarray(fm["precision"], dtype=float).reshape(-1)
+            out[key + "/fm_mean_precision"] = np.asarray(fm["mean_precision"], dtype=float).reshape(-1)
+    # Sampler level: the "LD" sampler of the demos (SGLD with the PaRIS gradient), three steps
+    for model, Sampler, mk, gen, dseed, eps in [("svm", SVMSampler, svm_params, generate_svm_data, 12345, 0.1),
+                                                ("garch", GARCHSampler, garch_params, generate_garch_data, 222, 0.01)]:
+        np.random.seed(dseed)
+        data = gen(T=120, parameters=mk())
+        y = data["observations"]
+        sampler = Sampler(n=1, m=1, observations=y, parameters=mk())
+        kwargs = dict(kind="pf", pf="paris", N=200, subsequence_length=16, buffer_length=4, minibatch_size=1)
+        np.random.seed(5150)
+        g = sampler.noisy_gradient(**kwargs)
+        np.random.seed(5151)
+        traj = [theta_of(model, sampler.parameters)]
+        for _ in range(3):
+            sampler.sample_sgld(epsilon=eps, **kwargs)
+            sampler.project_parameters()
+            traj.append(theta_of(model, sampler.parameters))
+        key = "s{0}".format(len(meta))
+        meta.append(dict(key=key, model=model, kind="sampler", N=200, eps=eps, kwargs=dict(subsequence_length=16, buffer_length=4)))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta0"] = theta_of(model, mk())
+        out[key + "/noisy_gradient"] = as_vec(model, g)
+        out[key + "/sgld_traj"] = np.array(traj)
+        out[key + "/next_draw"] = np.float64(np.random.random_sample())
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "paris_seed.npz"), **out)
+    print("paris_seed:", len(meta), "cases")
+
+
 def make_latent_fixtures():
     """Helper.pf_latent_var_distr (smoothed marginals via elementwise statistics)."""
     out, meta = {}, []
@@ -838,6 +914,8 @@ if __name__ == "__main__":
         make_theta_grid_fixtures()
     if only in ("", "cheader"):
         make_c_known_answer()
+    if only in ("", "paris_seed"):
+        make_paris_seed_fixtures()
     for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz", "theta_grid.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

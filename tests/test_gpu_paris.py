@@ -94,7 +94,7 @@ def test_paris_device_rng_statistics(ctx, model):
     y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
     kernel = "prior" if model == "svm" else "optimal"
     pm, pv = (0.0, 10.0) if model == "svm" else (0.0, float(po.garch_prior_x(p.theta())[1][0]))
-    probs = [make_problem(model, kernel, "paris", y, p.theta(), N, prior_mean=pm, prior_var=pv, seed=5, stream=b)
+    probs = [make_problem(model, kernel, "paris", y, p.theta(), N, prior_mean=pm, prior_var=pv, seed=5, stream=b, rng="device")
              for b in range(B)]
     assert probs[0]["rng"] == "device" and probs[0]["max_accept_reject"] == 64
     outs = ctx.run_batch(probs)
@@ -138,7 +138,7 @@ def test_paris_f32_and_filter_stat(ctx):
     res = {}
     for dtype in ("f64", "f32"):
         probs = [make_problem("lgssm", "optimal", "paris", y, p.theta(), 200, prior_var=10.0, seed=3, stream=b,
-                              dtype=dtype, stat="suff") for b in range(256)]
+                              dtype=dtype, stat="suff", rng="device") for b in range(256)]
         outs = ctx.run_batch(probs)
         res[dtype] = np.array([np.append(o["mean_stat"], o["loglik"]) for o in outs])
         assert np.all(np.isfinite(res[dtype])) and res[dtype].shape[1] == 4
@@ -181,3 +181,119 @@ def test_paris_randomised_pool_parity(ctx):
         np.testing.assert_allclose(o["all_statistics"], ref["all_statistics"], rtol=RTOL, atol=1e-8, err_msg=tag)
         np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8, err_msg=tag)
         assert abs(o["loglik"] - ref["loglikelihood_estimate"]) <= ATOL + RTOL * abs(ref["loglikelihood_estimate"]), tag
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 3: PaRIS seed for seed through the public API (the demos' "LD" sampler is SGLD on the PaRIS gradient,
+# demo/exchange_rate/exchange_rate_demo_gbp.py:66, 99-135).  rng='replay' (the default) with N <= 1024 consumes np.random
+# in the reference's order -- per timestep N uniforms, N normals, then the data-dependent run of uniforms of
+# accept_reject_based_backward_sampling (pf.py:260-341) -- so np.random.seed(s) reproduces the reference's numbers AND
+# leaves the generator where the reference leaves it.  Fixtures: tests/golden/paris_seed.npz (reference outputs).
+# ----------------------------------------------------------------------------------------------------------------------
+def _seed_cases(kind):
+    from conftest import Golden
+    g = Golden("paris_seed.npz")
+    return [(g, m) for m in g.meta if m["kind"] == kind]
+
+
+def _helper_for(g, m):
+    from sgmcmc_ssm_amd.models.svm import SVMHelper
+    from sgmcmc_ssm_amd.models.garch import GARCHHelper
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMHelper
+    HELPERS = {"svm": SVMHelper, "garch": GARCHHelper, "lgssm": LGSSMHelper}
+    key = m["key"]
+    fm = None
+    if m["has_forward_message"]:
+        fm = dict(log_constant=0.0, mean_precision=g.get(key, "fm_mean_precision").copy(),
+                  precision=g.get(key, "fm_precision").reshape(1, 1).copy())
+    return HELPERS[m["model"]](n=1, m=1, forward_message=fm)
+
+
+def _params_for(model, theta):
+    from sgmcmc_ssm_amd.models.svm import SVMParameters
+    from sgmcmc_ssm_amd.models.garch import GARCHParameters
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMParameters
+    if model == "svm":
+        return SVMParameters(A=np.eye(1) * theta[0], LQinv=np.eye(1) * theta[1], LRinv=np.eye(1) * theta[2])
+    if model == "lgssm":
+        return LGSSMParameters(A=np.eye(1) * theta[0], C=np.eye(1) * theta[1], LQinv=np.eye(1) * theta[2], LRinv=np.eye(1) * theta[3])
+    return GARCHParameters(log_mu=theta[0], logit_phi=theta[1], logit_lambduh=theta[2], LRinv=np.eye(1) * theta[3])
+
+
+@pytest.mark.parametrize("idx", range(9))
+def test_paris_helper_seed_for_seed(idx):
+    from test_host_logic import vec
+    g, m = _seed_cases("helper")[idx]
+    key = m["key"]
+    helper = _helper_for(g, m)
+    p = _params_for(m["model"], g.get(key, "theta"))
+    kw = dict(observations=g.get(key, "y").reshape(-1, 1), parameters=p, subsequence_start=m["t1"], subsequence_end=m["tL"],
+              weights=g.get(key, "weights"), pf="paris", N=m["N"], kernel=m["kernel"], **m["kwargs"])
+    np.random.seed(m["seed"])
+    grad = helper.pf_gradient_estimate(**kw)
+    nxt = np.random.random_sample()
+    ref = g.get(key, "grad")
+    np.testing.assert_allclose(vec(m["model"], grad), ref, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=str(m))
+    assert nxt == float(g.get(key, "next_draw")), m          # the generator stands where the reference's stands
+    np.random.seed(m["seed"])
+    ll = helper.pf_loglikelihood_estimate(**kw)
+    nxt = np.random.random_sample()
+    assert abs(ll - float(g.get(key, "loglik"))) <= 1e-9 * abs(float(g.get(key, "loglik"))), m
+    assert nxt == float(g.get(key, "next_draw_loglik")), m
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_paris_sampler_seed_for_seed(idx):
+    """Sampler.noisy_gradient / sample_sgld + project_parameters with pf='paris' (S = 16, B = 4 windows): the
+    reference's three-step trajectory after np.random.seed."""
+    from test_host_logic import SAMPLERS, vec
+    g, m = _seed_cases("sampler")[idx]
+    key = m["key"]
+    model = m["model"]
+    y = g.get(key, "y").reshape(-1, 1)
+    sampler = SAMPLERS[model][0](n=1, m=1, observations=y, parameters=_params_for(model, g.get(key, "theta0")))
+    kwargs = dict(kind="pf", pf="paris", N=m["N"], minibatch_size=1, **m["kwargs"])
+    np.random.seed(5150)
+    grad = sampler.noisy_gradient(**kwargs)
+    ref = g.get(key, "noisy_gradient")
+    np.testing.assert_allclose(vec(model, grad), ref, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    np.random.seed(5151)
+    traj = [sampler.parameters.theta().copy()]
+    for _ in range(3):
+        sampler.sample_sgld(epsilon=m["eps"], **kwargs)
+        sampler.project_parameters()
+        traj.append(sampler.parameters.theta().copy())
+    np.testing.assert_allclose(np.array(traj), g.get(key, "sgld_traj"), rtol=1e-9, atol=1e-11)
+    assert np.random.random_sample() == float(g.get(key, "next_draw"))
+
+
+def test_paris_stream_too_short_is_reported_and_retried(ctx):
+    """The kernel reports a stream that ran out (paris_consumed = -1) instead of reading past it; the host loop retries
+    the timestep with a longer block and ends at the same numbers."""
+    from sgmcmc_ssm_amd import particle_filters as pfm
+    g, m = _seed_cases("helper")[1]
+    key = m["key"]
+    N = m["N"]
+    rs = np.random.RandomState(1)
+    x = rs.normal(size=(N, 1))
+    q = dict(model="svm", kernel="prior", smoother="paris", stat="score", dtype="f64", rng="replay", N=N, t1=0, tL=1, lambduh=1.0,
+             theta=g.get(key, "theta"), prior_mean=0.0, prior_var=1.0, y=np.array([0.3]), init_x=x, init_logw=np.zeros(N),
+             init_stats=np.zeros((N, 3)), u=rs.random_sample((1, N)), z=rs.normal(size=(1, N)), Ntilde=2, max_accept_reject=30,
+             paris_manual_threshold=5)
+    short = ctx.run_batch([dict(q, paris_stream=rs.random_sample(N))], want_final=True)[0]
+    assert short["paris_consumed"] == -1
+    block = rs.random_sample(64 * N)
+    ok = ctx.run_batch([dict(q, paris_stream=block)], want_final=True)[0]
+    assert 2 * N < ok["paris_consumed"] < 64 * N
+    again = ctx.run_batch([dict(q, paris_stream=block[:ok["paris_consumed"]])], want_final=True)[0]      # exactly enough
+    assert again["paris_consumed"] == ok["paris_consumed"] and np.array_equal(again["statistics"], ok["statistics"])
+    # the hint-driven host loop: force a tiny first block
+    pfm._paris_block_hint[(m["N"], 3)] = 1
+    helper = _helper_for(g, m)
+    np.random.seed(m["seed"])
+    grad = helper.pf_gradient_estimate(observations=g.get(key, "y").reshape(-1, 1), parameters=_params_for("svm", g.get(key, "theta")),
+                                       subsequence_start=m["t1"], subsequence_end=m["tL"], weights=g.get(key, "weights"),
+                                       pf="paris", N=m["N"], **m["kwargs"])
+    from test_host_logic import vec
+    np.testing.assert_allclose(vec("svm", grad), g.get(key, "grad"), rtol=1e-9)
+    assert np.random.random_sample() == float(g.get(key, "next_draw"))

@@ -170,3 +170,39 @@ def test_theta_grid_oracle_bit_exact():
             assert out["loglikelihood_estimate"] == float(g.get(key, "loglikelihood_estimate")), meta
             assert np.array_equal(out["mean_statistic"], g.get(key, "mean_statistic")), meta
             assert np.array_equal(out["log_weights"], g.get(key, "log_weights")), meta
+
+
+def test_paris_seed_fixtures_oracle_bit_exact():
+    """Round 3: PaRIS through the reference's public entry points at the demos' particle count (paris_seed.npz): the
+    oracle in np.random order reproduces gradient and log-likelihood with abs-err 0.0 and leaves the generator where
+    the reference leaves it (the next draw), incl. accept_reject=False (pf.py:226-236) and non-default thresholds."""
+    from conftest import Golden
+    g = Golden("paris_seed.npz")
+    n = 0
+    for m in g.meta:
+        if m["kind"] != "helper":
+            continue
+        key = m["key"]
+        theta, y = g.get(key, "theta"), g.get(key, "y")
+        if m["model"] == "garch":
+            pm, pv = po.garch_prior_x(theta)
+            pv = float(np.asarray(pv).reshape(-1)[0])
+        else:
+            prec = float(g.get(key, "fm_precision")[0])
+            pv = 1.0 / prec
+            pm = float(g.get(key, "fm_mean_precision")[0]) / pv           # the reference's solve(prior_var, mean_precision)
+        kernel = m["kernel"] or po.DEFAULT_KERNEL[m["model"]]
+        for stat, ref_name, next_name in (("score", "grad", "next_draw"), ("suff", "loglik", "next_draw_loglik")):
+            rng = np.random.RandomState(m["seed"])
+            out = po.pf_window_paris_rng(m["model"], theta, y, m["N"], rng=rng, kernel=kernel, stat=stat, t1=m["t1"], tL=m["tL"],
+                                         weights=g.get(key, "weights"), prior_mean=pm, prior_var=pv, **m["kwargs"])
+            if stat == "score":
+                got = dict(zip(po.SCORE_NAMES[m["model"]], out["mean_statistic"]))
+                names = {"svm": ("A", "LQinv_vec", "LRinv_vec"), "lgssm": ("A", "C", "LQinv_vec", "LRinv_vec"),
+                         "garch": ("log_mu", "logit_phi", "logit_lambduh", "LRinv_vec")}[m["model"]]
+                assert np.array_equal(np.array([got[k] for k in names]), g.get(key, "grad")), m
+            else:
+                assert out["loglikelihood_estimate"] == float(g.get(key, "loglik")), m
+            assert rng.random_sample() == float(g.get(key, next_name)), (m, stat)
+        n += 1
+    assert n == 9
