@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void ews_step_kernel(int N, int Wd, int Nt, do
 // backward weights  bw_ij = softmax_j(logw_j + log q(x'_i | x_j)):
 //     S'[i][:] = sum_j bw_ij S[j][:]        block t:  += w_t sum_j bw_ij h(x_j, x'_i)
 // One workgroup per child: the N backward weights go to LDS once, then every thread owns columns and
-// walks the parents (rows of S stream through L2, coalesced over the column axis).  N <= 1024.
+// walks the parents (rows of S stream through L2, coalesced over the column axis).  N <= 4096.
 template <int MODEL>
 __global__ __launch_bounds__(256) void ews_n2_step_kernel(int N, int Wd, double wt, int col0,
                                                           const double *__restrict__ theta,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ews_n2_step_kernel(int N, int Wd, double 
                                                           const double *__restrict__ x_next,
                                                           const double *__restrict__ S, double *__restrict__ Sn) {
     constexpr int NS = ModelDims<MODEL>::NS;
-    __shared__ double bw[1024];
+    __shared__ double bw[4096];
     __shared__ double red[4];
     __shared__ double bx_s;
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

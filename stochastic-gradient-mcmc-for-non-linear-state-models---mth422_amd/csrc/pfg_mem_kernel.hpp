@@ -692,8 +692,96 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             }
             { REAL *tmp = lwg; lwg = lwn_g; lwn_g = tmp; }
         };
+        // Poyiadjis O(N^2) for 1024 < N <= 4096 (pf.py:84-136), in the PARIS instantiation (it has the second
+        // log-weight array, so the parents stay intact while the children are built): every child is proposed from
+        // its filter ancestor, then averages  stats_q + w_t h(x_q, child)  over ALL parents q with the backward
+        // weights  log_normalize(logw_q + log q(child | x_q)) -- two passes over the parents (exact maximum, then
+        // exp-sums), the parent records read with wave-uniform addresses from the L2-resident scratch.  One child
+        // chunk at a time: the arithmetic order is pf_reg_kernel's n2_slots.
+        auto n2_sweep = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            for (int j = 0; j < nchunk; ++j) {
+                const int i = j * NT + tid;
+                const bool v = i < N;
+                const int ii = v ? i : N - 1;
+                double u;
+                REAL z;
+                if (RNG == PFG_RNG_REPLAY) { u = uv[(size_t)t * N + ii]; z = (REAL)zv[(size_t)t * N + ii]; }
+                else { REAL zb; u = u01_32(rng.next()); mth.normal_pair(rng.next(), rng.next(), z, zb); }
+                int pos = 0;
+                for (int step = np2 >> 1; step >= 1; step >>= 1) {
+                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                    pos += (cdf[pos + probe] <= u) ? step + (step >> 5) : 0;
+                }
+                int a = pos - pos / 33;
+                a = a < N - 1 ? a : N - 1;
+                if (RNG == PFG_RNG_REPLAY && v) {
+                    const double hi = cdf[cdf_phys(a)] - u;
+                    const double lo = a > 0 ? u - cdf[cdf_phys(a - 1)] : 1.0;
+                    const double mg = hi < lo ? hi : lo;
+                    tie = mg < tie ? mg : tie;
+                }
+                REAL xp[NS], xn[NS], add[H], lwn;
+                alignas(16) REAL rec[REC];
+                rec_load<REC, REAL>(rec, cur + (size_t)a * REC);
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[d] = rec[d];
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z, xn, lwn, add);
+                const REAL aux = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[0]) : (REAL)0;
+                REAL mx = (REAL)(-INFINITY);
+#pragma unroll 2
+                for (int q = 0; q < N; ++q) {
+                    alignas(16) REAL rq[REC];
+                    rec_load<REC, REAL>(rq, cur + (size_t)q * REC);
+                    const REAL vq = lwg[q] + backward_log_ratio<MODEL, REAL>(c, mth, rq, xn);
+                    mx = vq > mx ? vq : mx;
+                }
+                REAL den = (REAL)0, num[H];
+#pragma unroll
+                for (int h = 0; h < H; ++h) num[h] = (REAL)0;
+#pragma unroll 2
+                for (int q = 0; q < N; ++q) {
+                    alignas(16) REAL rq[REC];
+                    rec_load<REC, REAL>(rq, cur + (size_t)q * REC);
+                    const REAL e = mth.exp((lwg[q] + backward_log_ratio<MODEL, REAL>(c, mth, rq, xn)) - mx);
+                    REAL aj[H];
+                    additive_stat<MODEL, STAT, REAL>(c, rq, xn, (REAL)y_t, aux, aj);
+                    den += e;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL av = use_stat ? aj[h] * (REAL)wt : (REAL)0;
+                        num[h] += e * (rq[NS + h] + av);
+                    }
+                }
+                if (v) {
+                    lwn_g[i] = lwn;
+#pragma unroll
+                    for (int q = 0; q < REC; ++q) rec[q] = (REAL)0;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) rec[d] = xn[d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) rec[NS + h] = num[h] / den;
+                    rec_store<REC, REAL>(nxt + (size_t)i * REC, rec);
+                    if (P.trace_x) {
+                        const size_t row = (size_t)(t + 1) * N + i;
+                        if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = a;
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)xn[d];
+                        P.trace_logw[row] = (double)lwn;
+                        if (P.trace_stats) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)rec[NS + h];
+                        }
+                    }
+                }
+            }
+            { REAL *tmp = lwg; lwg = lwn_g; lwn_g = tmp; }
+        };
         if constexpr (PARIS) {
-            if (stat == PFG_STAT_SCORE) paris_sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+            if (P.smoother == PFG_SMOOTHER_POYIADJIS_N2) {
+                if (stat == PFG_STAT_SCORE) n2_sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+                else n2_sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+            } else if (stat == PFG_STAT_SCORE) paris_sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
             else paris_sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
         } else {
             if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});

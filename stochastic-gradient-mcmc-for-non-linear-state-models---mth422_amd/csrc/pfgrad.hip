@@ -168,7 +168,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                         : v == kVariantBig ? (n_max <= 4096 ? "big4096" : "big16384")
                         : v == kVariantParis ? (n_max <= 256 ? "paris256x1" : n_max <= 1024 ? "paris256x4" : "paris_mem1024")
                         : v == kVariantSystematic ? "systematic256x4"
-                        : (n_max <= 256 ? "n2_256x1" : "n2_256x4");
+                        : (n_max <= 256 ? "n2_256x1" : n_max <= 1024 ? "n2_256x4" : "n2_mem1024");
     ctx->last_traced = traced || v < 0 || rng == PFG_RNG_REPLAY;
     if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
     if (model == PFG_MODEL_GARCH) {
@@ -614,8 +614,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
         if ((q.smoother == PFG_SMOOTHER_POYIADJIS_N2) != (ps[0].smoother == PFG_SMOOTHER_POYIADJIS_N2))
             return fail(ctx, PFG_ERR_INVALID, id + "pf = 'poyiadjis_N2' cannot share a batch with other smoothers");
-        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.N > 1024)
-            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'poyiadjis_N2' is implemented for N <= 1024");
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.N > 4096)
+            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'poyiadjis_N2' is implemented for N <= 4096");
         if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.stat == PFG_STAT_PREDICTIVE)
             return fail(ctx, PFG_ERR_INVALID, id + "Only can use pf = 'filter' since we are filtering");
         if ((q.smoother == PFG_SMOOTHER_PARIS) != (ps[0].smoother == PFG_SMOOTHER_PARIS))
@@ -749,7 +749,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
     size_t n_scratch = 0;                  // bytes; every window of the batch gets n_max-sized state
     const size_t pred_each = predictive ? ((size_t)n_max * PFG_MAX_PRED * (dtype == PFG_F64 ? 8 : 4) + 255) / 256 * 256 : 0;
-    const bool paris_mem = paris && n_max > 1024;
+    const bool paris_mem = (paris || n2) && n_max > 1024;       // the large-N kernel's PaRIS instantiation (also its O(N^2) sweep)
     const size_t scratch_each = (scratch_bytes(model, dtype, n_max, paris_mem) + 255) / 256 * 256 + pred_each;
     if (variant == kVariantMem || paris_mem) n_scratch = scratch_each * (size_t)B;
 

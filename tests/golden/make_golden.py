@@ -633,6 +633,38 @@ def make_n2_fixtures():
     np.savez_compressed(os.path.join(HERE, "n2.npz"), **out)
 
 
+
+def make_n2_large_fixtures():
+    """poyiadjis_smoother O(N^2) (pf.py:84-136, no limit on N) at N = 2000 and 4096 -- beyond the LDS-resident kernel:
+    reference outputs of short windows (mean statistic, log-likelihood, the first 64 particles' statistics)."""
+    out, meta = {}, []
+    cases = [("svm", "prior", "score", 2000, 4, 1, 4, True, 3300), ("garch", "optimal", "score", 2000, 3, 0, 3, False, 3301),
+             ("lgssm", "optimal", "suff", 1500, 3, 0, 2, True, 3302), ("svm", "prior", "score", 4096, 2, 0, 2, False, 3303)]
+    for model, kernel, stat, N, T, t1, tL, use_w, seed in cases:
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(seed + 50000)
+        data = cfg["gen"](T=T, parameters=p)
+        y = data["observations"]
+        pm, pv = prior_x(model, p, data)
+        weights = (1.0 + 0.5 * np.arange(tL - t1)) if use_w else None
+        res = run_window(model, kernel, "poyiadjis_N2", stat, p, y, N, t1, tL, weights, pm, pv, seed)
+        key = "n{0}".format(len(meta))
+        meta.append(dict(key=key, model=model, kernel=kernel, pf="poyiadjis_N2", stat=stat, lambduh=None, N=N, T=T, t1=t1, tL=tL,
+                         seed=seed, prior_mean=pm, prior_var=pv, has_weights=bool(use_w), traced=False))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        if weights is not None:
+            out[key + "/weights"] = weights
+        out[key + "/mean_statistic"] = np.asarray(res["mean_statistic"], dtype=float)
+        out[key + "/loglikelihood_estimate"] = np.float64(res["loglikelihood_estimate"])
+        out[key + "/statistics_head"] = np.asarray(res["statistics"], dtype=float)[:64]
+        out[key + "/x_t_head"] = np.asarray(res["x_t"], dtype=float)[:64]
+        print(key, model, N, "done", flush=True)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "n2_large.npz"), **out)
+
+
 def make_sgrld_fixtures():
     """SGRLD / SGRD with the LGSSM preconditioner on particle-filter gradients
     (sgmcmc_sampler.py:486-502, 613-640; covariance.py:286-317; matrices.py:632-656, 1099-1125)."""
@@ -916,6 +948,8 @@ if __name__ == "__main__":
         make_c_known_answer()
     if only in ("", "paris_seed"):
         make_paris_seed_fixtures()
+    if only in ("", "n2_large"):
+        make_n2_large_fixtures()
     for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz", "theta_grid.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -102,7 +102,50 @@ def test_n2_device_rng_and_f32(ctx, model, kernel):
     # the O(N^2) estimator has the smaller variance (that is its point)
     assert res[("f64", "poyiadjis_n2")].var(axis=0)[:2].sum() < res[("f64", "nemeth")].var(axis=0)[:2].sum() * 1.5
     with pytest.raises(NotImplementedError):
-        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", N=2000, stream=1)])
+        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", N=5000, stream=1)])
     with pytest.raises(ValueError):
         ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", stream=1),
                        dict(base, smoother="nemeth", dtype="f64", stream=2)])
+
+
+def test_n2_beyond_lds_vs_reference(ctx):
+    """1024 < N <= 4096 (round 3): the O(N^2) sweep of the large-N kernel (state in the HBM scratch, parents read with
+    wave-uniform addresses) against REFERENCE outputs at N = 1500 / 2000 / 4096 (tests/golden/n2_large.npz; pf.py:84-136
+    has no limit on N), REPLAY fp64, rtol 1e-9."""
+    g = Golden("n2_large.npz")
+    assert [m["N"] for m in g.meta] == [2000, 2000, 1500, 4096]
+    for m in g.meta:
+        key = m["key"]
+        q = _problem(m, g)
+        o = ctx.run_batch([q], want_final=True)[0]
+        assert ctx.last_variant() == "n2_mem1024"
+        ll = float(g.get(key, "loglikelihood_estimate"))
+        assert abs(o["loglik"] - ll) <= ATOL + RTOL * abs(ll), (m, o["loglik"], ll)
+        ref = g.get(key, "mean_statistic")
+        assert np.linalg.norm(o["mean_stat"] - ref) <= 1e-8 * max(1.0, np.linalg.norm(ref)), (m, o["mean_stat"], ref)
+        np.testing.assert_allclose(o["statistics"][:64], g.get(key, "statistics_head"), rtol=RTOL, atol=1e-8, err_msg=str(m))
+        np.testing.assert_allclose(o["x_t"][:64], g.get(key, "x_t_head"), rtol=RTOL, atol=ATOL, err_msg=str(m))
+
+
+def test_n2_beyond_lds_device_rng_and_oracle(ctx):
+    """N = 3000: device generator (finite, close to the O(N) estimate) and REPLAY against the oracle incl. the full
+    per-particle statistics."""
+    rs = np.random.RandomState(9)
+    theta = np.array([0.95, 0.5 ** -0.5, 0.5 ** -0.5])
+    N, T = 3000, 3
+    y = rs.normal(size=T) * 1.2
+    z0, u, z = po.draw_streams(rs, N, T)
+    ref = po.pf_window("svm", theta, y, N, z0, u, z, kernel="prior", pf="poyiadjis_N2", stat="score", prior_mean=0.0, prior_var=2.0)
+    q = dict(model="svm", kernel="prior", smoother="poyiadjis_n2", stat="score", dtype="f64", rng="replay", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=y, theta=theta, z0=z0, u=u, z=z)
+    o = ctx.run_batch([q], want_final=True)[0]
+    np.testing.assert_allclose(o["statistics"], ref["statistics"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8)
+    assert abs(o["loglik"] - ref["loglikelihood_estimate"]) < 1e-9
+    base = dict(model="svm", kernel="prior", stat="score", N=N, t1=0, tL=T, lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=y,
+                theta=theta, rng="device", seed=3, dtype="f64")
+    a = np.array([o["mean_stat"] for o in ctx.run_batch([dict(base, smoother="poyiadjis_n2", stream=s) for s in range(6)])])
+    b = np.array([o["mean_stat"] for o in ctx.run_batch([dict(base, smoother="nemeth", stream=s) for s in range(6)])])
+    assert np.all(np.isfinite(a))
+    sd = np.sqrt(a.var(axis=0) / 6 + b.var(axis=0) / 6) + 1e-3
+    assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 6 * sd + 0.05 * np.abs(b.mean(axis=0)))
