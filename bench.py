@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
 N_CU = 256
 
-RNG_PRECISION = ("device generator: xoshiro128++ per lane keyed by Philox4x32-10(seed; lane, global chain id, step); "
+RNG_PRECISION = ("device generator: jsf32 per lane keyed by Philox4x32-10(seed; lane, global chain id, step); "
                  "32-bit uniforms searched against a 32-bit fixed-point CDF (LDS-resident kernels) or an fp64 CDF "
                  "(large-N kernel); Box-Muller normals evaluated on the f32 transcendental units (v_log/v_sin/v_cos) "
                  "and widened to f64; all arithmetic on the particle state, weights, CDF sums and statistics is fp64")

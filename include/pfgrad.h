@@ -73,7 +73,7 @@ enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2,
 /* particle-state arithmetic type.  Weight normalisation, CDF and search are always f64. */
 enum pfg_dtype { PFG_F64 = 0, PFG_F32 = 1 };
 /* REPLAY: caller supplies the NumPy legacy stream (z0[N], u[T*N], z[T*N]) -> results
- * reproduce the reference on the same seed.  DEVICE: generated in the kernel: one xoshiro128++
+ * reproduce the reference on the same seed.  DEVICE: generated in the kernel: one jsf32
  * generator per lane keyed by Philox4x32-10(seed; lane, stream, *step_ctr); 32-bit uniforms,
  * Box-Muller normals evaluated on the f32 transcendental units and widened. */
 enum pfg_rng { PFG_RNG_REPLAY = 0, PFG_RNG_DEVICE = 1 };

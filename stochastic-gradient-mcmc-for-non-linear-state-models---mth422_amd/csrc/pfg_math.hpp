@@ -107,14 +107,21 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 }
 
 // ------------------------------------------------------------------------------------
-// Device RNG (PFG_RNG_DEVICE): one xoshiro128++ generator per lane (Blackman & Vigna 2019;
-// adds / xors / rotates only -- 32-bit multiplies are quarter-rate on CDNA), its 128-bit state
-// keyed by Philox4x32-10(seed; lane, stream = global chain id, step counter), so streams are
-// reproducible and independent of how chains are spread over GPUs.
+// Device RNG (PFG_RNG_DEVICE): one small generator per lane, its 128-bit state keyed by
+// Philox4x32-10(seed; lane, stream = global chain id, step counter), so streams are reproducible and independent
+// of how chains are spread over GPUs.  Default: jsf32 (Jenkins' small fast generator, two-rotate form 27 / 17:
+// adds, xors and rotates only -- 32-bit multiplies are quarter-rate on CDNA --, 7 instructions per word, eight
+// warm-up rounds behind the key); -DPFG_RNG_XOSHIRO=1 builds xoshiro128++ (Blackman & Vigna 2019, 11 instructions per
+// word) instead.  Round 2 measured no difference between the two (15.74 vs 15.78 ms per launch: the kernel then
+// stalled elsewhere); with the LDS stalls of round 3 gone the shorter generator is worth 1.3-2.8 % on every config
+// (ms per bench launch, xoshiro / jsf32: SVM 46.8 / 45.5, N = 4000 12.23 / 11.92, GARCH windows 2.71 / 2.67, one wave
+// 1.73 / 1.70, N = 10000 6.79 / 6.70; profiles/r03_ab_jsf32.txt).  The draws are inputs of the filter; their
+// distribution is tested on what the kernels record (tests/test_gpu_device_replay.py::test_recorded_draws_are_standard,
+// tests/test_gpu_ensemble.py::test_device_generator_normals_and_uniform_streams).
 // ------------------------------------------------------------------------------------
 struct LaneRng {
     uint32_t s0, s1, s2, s3;
-#ifndef PFG_RNG_JSF32
+#ifdef PFG_RNG_XOSHIRO
     __device__ __forceinline__ uint32_t next() {        // xoshiro128++: 11 instructions per word
         const uint32_t sum = s0 + s3;
         const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
@@ -125,11 +132,7 @@ struct LaneRng {
         return result;
     }
 #else
-    // -DPFG_RNG_JSF32: jsf32 (Jenkins' small fast generator, two-rotate form 27/17), 7 instructions
-    // per word against xoshiro128++'s 11.  Measured: no difference in kernel time (15.74 vs 15.78 ms
-    // per bench launch) -- the generator's integer work fills issue slots the dependency chains leave
-    // empty -- so the default stays xoshiro128++.
-    __device__ __forceinline__ uint32_t next() {
+    __device__ __forceinline__ uint32_t next() {        // jsf32: 7 instructions per word
         const uint32_t e = s0 - ((s1 << 27) | (s1 >> 5));
         s0 = s1 ^ ((s2 << 17) | (s2 >> 15));
         s1 = s2 + s3;
@@ -145,8 +148,8 @@ __device__ __forceinline__ LaneRng lane_rng_init(uint64_t seed, uint64_t stream,
                              (uint32_t)(stream >> 32) ^ (uint32_t)(step >> 32)},
                             (uint32_t)seed, (uint32_t)(seed >> 32));
     LaneRng g;
-    g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w | 1u;   // never the all-zero state
-#ifdef PFG_RNG_JSF32
+    g.s0 = r.x; g.s1 = r.y; g.s2 = r.z; g.s3 = r.w | 1u;   // never the all-zero state (a fixed point of both generators)
+#ifndef PFG_RNG_XOSHIRO
 #pragma unroll
     for (int q = 0; q < 8; ++q) (void)g.next();             // jsf32: mix the key into all four words
 #endif

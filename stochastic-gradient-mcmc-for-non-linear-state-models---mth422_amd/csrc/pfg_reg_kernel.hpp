@@ -196,6 +196,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     // order a thread's PPT weights are contiguous: one in-register prefix + ONE wave scan per
     // thread instead of PPT wave scans.  REPLAY keeps the reference's index order (parity).
     constexpr bool BLK = FAST && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN && (PPT & (PPT - 1)) == 0;
+    // SORTED (the 1024-thread device-generator variant, N <= 4096): the N resampling uniforms of a timestep are drawn
+    // as the ORDER STATISTICS of N i.i.d. uniforms -- exponential spacings e_r = -log u_r, U_(r) = sum_{q<=r} e_q /
+    // sum_{q<=N+1} e_q, by a second prefix scan that rides on the weight scan's barriers -- and child r takes U_(r)
+    // (multinomial resampling does not care which child gets which uniform; children are exchangeable).  CDF and
+    // ranks both run in thread-major order, so neighbouring lanes search neighbouring keys (coherent probes: LDS
+    // broadcasts instead of bank conflicts) and gather neighbouring parents.  One such workgroup fills a CU's LDS, so
+    // nothing else hides its LDS stalls: the knock-out with evenly spaced words was worth 15 % there (4 % on the
+    // 256-thread SVM kernel, where the second scan costs more than that).  -DPFG_OPT_SORTED1024=0 restores i.i.d. words.
+#ifndef PFG_OPT_SORTED1024
+#define PFG_OPT_SORTED1024 1
+#endif
+    constexpr bool SORTED = PFG_OPT_SORTED1024 && BLK && NT == 1024 && PPT == 4 && !systematic && NW > 1;
     constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : (PPT == 8 ? 3 : 4)));
     static_assert(PPT <= 16, "LOG_PPT covers 1, 2, 4, 8, 16 particles per thread");
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
@@ -373,6 +385,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             }
         }
         double wave_inc = 0.0;          // BLK: this wave's inclusive scan (lane 63 = the wave total)
+        double es[PPT];                 // SORTED: inclusive prefix of the exponential spacings of this thread's children
+        uint32_t us[PPT];               // SORTED: the sorted uniforms as 32-bit fixed point
         if (BLK) {
 #pragma unroll
             for (int k = 1; k < PPT; ++k) cs[k] += cs[k - 1];
@@ -382,6 +396,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) cs[k] += exc;
             if (NW > 1 && lane == WAVE - 1) red_scan[wave] = inc;
             wave_inc = inc;
+            if (SORTED && t < T) {
+                // exponential spacings of this thread's (valid) children, thread-local prefix + one wave scan; the
+                // (N+1)-th spacing rides in the last wave's total
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const double e = (double)spacing_f32(rng.next());
+                    es[k] = (valid[k] ? e : 0.0) + (k > 0 ? es[k - 1] : 0.0);
+                }
+                double einc = wave_incl_scan(es[PPT - 1]);
+                const double eexc = einc - es[PPT - 1];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) es[k] += eexc;
+                if (lane == WAVE - 1) {
+                    if (wave == NW - 1) einc += (double)spacing_f32(rng.next());
+                    red_scan[NW + wave] = einc;
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -422,6 +453,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) cs[k] += off;
             W = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), NW - 1),
                                  __builtin_amdgcn_readlane(__double2loint(inc), NW - 1));
+            if (SORTED && t < T) {
+                const double totE = (lane < NW) ? red_scan[NW + lane] : 0.0;
+                double incE = totE;
+                incE += dpp_shr0_f64<0x111>(incE);
+                incE += dpp_shr0_f64<0x112>(incE);
+                incE += dpp_shr0_f64<0x114>(incE);
+                incE += dpp_shr0_f64<0x118>(incE);
+                const double excE = incE - totE;
+                const double offE = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(excE), wave),
+                                                     __builtin_amdgcn_readlane(__double2loint(excE), wave));
+                const double Etot = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incE), NW - 1),
+                                                     __builtin_amdgcn_readlane(__double2loint(incE), NW - 1));
+                double r = __builtin_amdgcn_rcp(Etot);
+                r = fma(fma(-Etot, r, 1.0), r, r);
+                r = fma(fma(-Etot, r, 1.0), r, r);
+                const double fe = uniform_f64(r * 4294967296.0);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) us[k] = cvt_u32_sat((es[k] + offE) * fe);
+            }
         } else if (PPT * NW <= 16) {
             // lane j < PPT*NW holds total j; exclusive prefix by a 16-lane DPP scan; each thread
             // picks its PPT offsets and the grand total with v_readlane (uniform indices)
@@ -546,7 +596,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         if (BLK) {
             uint32_t ua[PPT];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) ua[k] = rng.next();
+            for (int k = 0; k < PPT; ++k) ua[k] = SORTED ? us[k] : rng.next();
 #ifdef PFG_EXP_EVENWORDS
             // knock-out (timing only, NOT a valid resampler): evenly spaced words in CDF order -- what sorted uniforms
             // would do to the LDS bank conflicts of the search and the gathers, without their cost

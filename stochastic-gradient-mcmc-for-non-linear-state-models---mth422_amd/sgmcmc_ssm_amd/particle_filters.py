@@ -10,7 +10,7 @@ RNG modes
       legacy `np.random` state are drawn here, in the same order (N normals for x0, then per
       timestep N uniforms for np.random.choice and N normals for Kernel.rv), and handed to the
       kernel.  Results then reproduce the reference on identical seeds (fp64).
-  rng='device' (alias 'philox'): generated inside the kernel (one xoshiro128++ per lane keyed
+  rng='device' (alias 'philox'): generated inside the kernel (one jsf32 per lane keyed
       by Philox4x32-10 of (seed, stream, step)): no host stream, no H2D traffic; the fast path,
       statistically equivalent, not seed-compatible with the reference.
 
