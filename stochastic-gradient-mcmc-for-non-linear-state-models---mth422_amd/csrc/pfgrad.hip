@@ -74,7 +74,7 @@ size_t lds_bytes(int model, int dtype, int rng, const Variant &v, int N) {
     size_t tab = (fast && dtype == PFG_F64)
                      ? 8 * (size_t)(pfg::tab_doubles_exp(rng == PFG_RNG_DEVICE) + (rng == PFG_RNG_DEVICE ? pfg::TAB_DOUBLES_RNG : 0)) : 0;
     const bool blk = fast && rng == PFG_RNG_DEVICE;        // 32-bit fixed-point CDF (pfg::pf_reg_kernel)
-    const size_t NLS = NL + (fast ? (size_t)(PFG_OPT_PADSTATE ? 8 / rs : 0) : 0);      // pfg::state_pad
+    const size_t NLS = NL + ((fast && rng == PFG_RNG_DEVICE) ? (size_t)(PFG_OPT_PADSTATE ? 8 / rs : 0) : 0);      // pfg::state_pad
     return (NC * (blk ? 4 : 8) + 15) / 16 * 16 + (v.pp ? 2 : 1) * NLS * (state_dim(model) + stat_dim(model)) * rs + red * 8 + tab;
 }
 

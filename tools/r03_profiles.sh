@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in $CFGS; do
   OUT=/root/repo/gpurun_out/r03_prof/$c
   rm -rf $OUT; mkdir -p $OUT
-  (python3 -c "import bench; print(bench.kernel_source_sha())") > $OUT/source_sha.txt
+  (cd /root/repo && python3 -c "import bench; print(bench.kernel_source_sha())") > $OUT/source_sha.txt
   ARGS="--config $c --steps 5 --warmup 1 --no-cpu-baseline --no-single-chain"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 /root/repo/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
   rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT \
