@@ -125,7 +125,7 @@ typedef struct pfg_problem {
      * statistic matrix through HBM step by step.  NEMETH (any lambduh) and PARIS. */
     int32_t elementwise;
     const double *pred_z;
-    /* PaRIS in the REFERENCE's np.random order (REPLAY, N <= 1024): ONE sequential stream of uniforms, consumed as
+    /* PaRIS in the REFERENCE's np.random order (REPLAY): ONE sequential stream of uniforms, consumed as
      * accept_reject_based_backward_sampling does (pf.py:260-341): per draw j and round, len(L) doubles for
      * np.random.choice then len(L) for np.random.rand, the k-th pending child in index order taking the k-th of each;
      * once <= paris_manual_threshold children are left (or after max_accept_reject rounds) one double per child for

@@ -174,6 +174,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     __syncthreads();
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
+    long long paris_cursor = 0;            // PaRIS in the reference's stream order (see pf_reg_kernel): doubles consumed
+    bool paris_overflow = false;
     double filt[H], S[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) { filt[h] = 0.0; S[h] = 0.0; }
@@ -493,12 +495,91 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 // wave is pending, K = 2^k consecutive rounds per child and pass below that
                 int *qa = wq0 + wave * (nchunk * WAVE), *qb = wq1 + wave * (nchunk * WAVE);
                 int cnt = 0;
+                const bool ordered = RNG == PFG_RNG_REPLAY && P.paris_stream != nullptr;
+                if (ordered) {
+                    // the REFERENCE's consumption order (pf.py:260-341), as in pf_reg_kernel's paris_slots: per round the
+                    // k-th pending child IN INDEX ORDER takes the k-th double of the round's two blocks; the rank = a
+                    // workgroup-wide exclusive count of the pending flags (chunk-major = particle-index order)
+                    const double *__restrict__ const strm = P.paris_stream;
+                    const long long cap = P.paris_stream_len;
+                    const bool noar = (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) != 0;
+                    const int mthr = P.paris_manual_threshold;
+                    int *const wcnt = reinterpret_cast<int *>(red_scan);     // [nchunk][NW] (free outside phases B-D)
+                    int *const woff = reinterpret_cast<int *>(red_off);      // [nchunk][NW] exclusive offsets, [256] = total
+                    uint32_t pend = 0;
+                    for (int j = 0; j < nchunk; ++j) pend |= (j * NT + tid < N) ? (1u << j) : 0u;
+                    int Stot = 0;
+                    for (int round = 0;; ++round) {
+                        for (int j = 0; j < nchunk; ++j) {
+                            const unsigned long long mk = __ballot((pend >> j) & 1u);
+                            if (lane == 0) wcnt[j * NW + wave] = __popcll(mk);
+                        }
+                        __syncthreads();
+                        if (wave == 0) {
+                            const int ntot = nchunk * NW;
+                            double v4[4], loc = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int idx = lane * 4 + q;
+                                v4[q] = idx < ntot ? (double)wcnt[idx] : 0.0;
+                                loc += v4[q];
+                            }
+                            const double inc = wave_incl_scan(loc);
+                            double run = inc - loc;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int idx = lane * 4 + q;
+                                if (idx < ntot) woff[idx] = (int)run;
+                                run += v4[q];
+                            }
+                            if (lane == WAVE - 1) woff[MEM_MAX_CHUNKS * NW] = (int)inc;
+                        }
+                        __syncthreads();
+                        Stot = woff[MEM_MAX_CHUNKS * NW];
+                        if (Stot == 0 || noar || Stot <= mthr || round >= R || paris_overflow) break;
+                        if (paris_cursor + 2ll * Stot > cap) { paris_overflow = true; break; }
+                        for (int j = 0; j < nchunk; ++j) {
+                            const bool pj = (pend >> j) & 1u;
+                            const unsigned long long mk = __ballot(pj);
+                            if (!pj) continue;
+                            const int i = j * NT + tid;
+                            const int rank = woff[j * NW + wave] + __popcll(mk & ltmask);
+                            const double u1 = strm[paris_cursor + rank], u2 = strm[paris_cursor + Stot + rank];
+                            const int I = search(u1);
+                            REAL xI[NS], xc[NS];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)I * REC + d]; xc[d] = nxt[(size_t)i * REC + d]; }
+                            const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
+                            if (u2 <= thr) { contribute(i, I); pend &= ~(1u << j); }
+                        }
+                        paris_cursor += 2ll * Stot;
+                        __syncthreads();                           // woff / wcnt are rewritten by the next round
+                    }
+                    if (Stot > 0 && !noar && paris_cursor + Stot > cap) paris_overflow = true;
+                    if (Stot > 0 && noar && (long long)N * Nt > cap) paris_overflow = true;
+                    if (!paris_overflow && Stot > 0) {
+                        for (int j = 0; j < nchunk; ++j) {
+                            const bool pj = (pend >> j) & 1u;
+                            const unsigned long long mk = __ballot(pj);
+                            if (!pj) continue;
+                            const int i = j * NT + tid;
+                            const int rank = woff[j * NW + wave] + __popcll(mk & ltmask);
+                            qchild[rank] = i;
+                            qum[rank] = (REAL)(noar ? strm[(long long)i * Nt + jt] : strm[paris_cursor + rank]);
+                        }
+                        if (tid == 0) *qcount = Stot;
+                        if (!noar) paris_cursor += Stot;
+                    }
+                    __syncthreads();
+                }
+                if (!ordered) {
                 for (int j = 0; j < nchunk; ++j) {
                     const int i = j * NT + tid;
                     const bool v = i < N;
                     const unsigned long long mk = __ballot(v);
                     if (v) qa[cnt + __popcll(mk & ltmask)] = i;
                     cnt += __popcll(mk);
+                }
                 }
                 auto candidate = [&](int child, int round, bool act, int &Iout) {
                     double u1, u2;
@@ -802,6 +883,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         tie = red_max[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
+    }
+    if (PARIS && tid == 0 && P.paris_consumed) {
+        if (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) paris_cursor = (long long)N * P.Ntilde * T;
+        *P.paris_consumed = paris_overflow ? -1ll : paris_cursor;
     }
     if (tid == 0 && P.out) {
 #pragma unroll

@@ -143,6 +143,9 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 #ifndef PFG_OPT_SEL32
 #define PFG_OPT_SEL32 1
 #endif
+#ifndef PFG_OPT_PIVOTS
+#define PFG_OPT_PIVOTS 0
+#endif
 #else
 #undef PFG_OPT_LAZYLL
 #undef PFG_OPT_RCPW
@@ -150,6 +153,8 @@ __host__ __device__ constexpr int occ_min(int NT, int PPT, size_t real, bool PP,
 #define PFG_OPT_RCPW 0
 #undef PFG_OPT_SEL32
 #define PFG_OPT_SEL32 0
+#undef PFG_OPT_PIVOTS
+#define PFG_OPT_PIVOTS 0
 #endif
 // The device-generator SVM single-buffer workgroup needs 39.5 KB of LDS with the 32-bit CDF:
 // FOUR workgroups fit a CU if the kernel stays within 128 VGPRs (34 spilled registers; measured
@@ -619,8 +624,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             uint32_t off[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) off[k] = cdf_base;
+            // PIVOTS (A/B, -DPFG_OPT_PIVOTS=1; 1024 slots): the three entries the first two levels of every search
+            // compare with (positions 511, 255, 767) are read ONCE per wave and timestep (broadcast reads) and held in
+            // scalar registers: two dependent LDS round trips and eight ds_read per lane-timestep less
+            constexpr bool PIVOTS = PFG_OPT_PIVOTS && NT * PPT == 1024;
+            constexpr int FIRST_STEP = PIVOTS ? 128 : (NT * PPT) >> 1;
+            if constexpr (PIVOTS) {
+                const uint32_t p511 = __builtin_amdgcn_readfirstlane(cdfu[cdf_phys(511)]);
+                const uint32_t p255 = __builtin_amdgcn_readfirstlane(cdfu[cdf_phys(255)]);
+                const uint32_t p767 = __builtin_amdgcn_readfirstlane(cdfu[cdf_phys(767)]);
 #pragma unroll
-            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                for (int k = 0; k < PPT; ++k) {
+                    const bool g1 = p511 <= ua[k];
+                    const uint32_t t2 = g1 ? p767 : p255;
+                    const bool g2 = t2 <= ua[k];
+                    off[k] += (g1 ? 4u * (512 + 16) : 0u) + (g2 ? 4u * (256 + 8) : 0u);
+                }
+            }
+#pragma unroll
+            for (int step = FIRST_STEP; step >= 1; step >>= 1) {
                 const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
                 const int adv = step + (step >> 5);
                 uint32_t cv[PPT];

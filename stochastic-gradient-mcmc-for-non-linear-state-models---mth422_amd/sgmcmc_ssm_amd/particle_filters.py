@@ -252,17 +252,17 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
     paris_kw = {}
     if smoother == "paris":
         # PaRIS (pf.py:183-341).  Its backward-sampling draws are data dependent in number and interleave with the
-        # filter's draws in np.random's order.  rng='replay' with N <= 1024 reproduces that order exactly: the
+        # filter's draws in np.random's order.  rng='replay' (N <= 16384) reproduces that order exactly: the
         # window runs here and now, one kernel launch per timestep (_paris_replay_window), so that np.random.seed(s)
         # gives the reference's numbers and leaves the generator where the reference leaves it.  Explicit uniform
-        # pools (tests) use the addressed form; larger N and rng='device' use the device generator, keyed from
+        # pools (tests) use the addressed form; rng='device' uses the device generator, keyed from
         # np.random (reproducible under np.random.seed, statistically equivalent to the reference).
         accept_reject = bool(kwargs.pop("accept_reject", True))
         mst = kwargs.pop("manual_sample_threshold", None)
         mar = kwargs.pop("max_accept_reject", None)
         paris_kw["Ntilde"] = int(kwargs.pop("Ntilde", 2))
         pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
-        if rng == "replay" and pools[2] is None and int(N) <= 1024 and stat in ("score", "suff") and dtype == "f64":
+        if rng == "replay" and pools[2] is None and int(N) <= 16384 and stat in ("score", "suff") and dtype == "f64":
             q = dict(model=model, kernel=kernel, smoother="paris", stat=stat, dtype=dtype, rng="replay", N=int(N),
                      t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=1.0, Ntilde=paris_kw["Ntilde"],
                      prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),

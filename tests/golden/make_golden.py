@@ -425,7 +425,10 @@ def make_paris_seed_fixtures():
              ("garch", "prior", 300, 12, 2, 10, dict(Ntilde=1)),
              ("lgssm", None, 1000, 24, 4, 20, dict()),
              ("lgssm", "prior", 257, 10, 0, 10, dict(accept_reject=False, Ntilde=3)),
-             ("lgssm", None, 64, 10, 2, 9, dict(manual_sample_threshold=0))]
+             ("lgssm", None, 64, 10, 2, 9, dict(manual_sample_threshold=0)),
+             # beyond the LDS-resident kernel (N > 1024): the large-N kernel's stream-order mode
+             ("svm", None, 2500, 10, 2, 9, dict()),
+             ("garch", None, 1500, 8, 0, 8, dict(Ntilde=1, max_accept_reject=6))]
     for ci, (model, kernel, N, T, t1, tL, kw) in enumerate(cases):
         cfg = MODEL_SETUP[model]
         p = cfg["params"]()

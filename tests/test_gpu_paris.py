@@ -220,7 +220,7 @@ def _params_for(model, theta):
     return GARCHParameters(log_mu=theta[0], logit_phi=theta[1], logit_lambduh=theta[2], LRinv=np.eye(1) * theta[3])
 
 
-@pytest.mark.parametrize("idx", range(9))
+@pytest.mark.parametrize("idx", range(11))
 def test_paris_helper_seed_for_seed(idx):
     from test_host_logic import vec
     g, m = _seed_cases("helper")[idx]

@@ -205,4 +205,4 @@ def test_paris_seed_fixtures_oracle_bit_exact():
                 assert out["loglikelihood_estimate"] == float(g.get(key, "loglik")), m
             assert rng.random_sample() == float(g.get(key, next_name)), (m, stat)
         n += 1
-    assert n == 9
+    assert n == 11
