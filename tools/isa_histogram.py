@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--flags", default="", help="extra compiler flags, space separated in ONE argument")
     ap.add_argument("--write", default=None)
     ap.add_argument("--blocks", action="store_true", help="also list the blocks with their weights")
+    ap.add_argument("--pmc", default=None, help="key,waves_per_workgroup,timesteps+1: print the measured SQ_INSTS_VALU per "
+                    "wave-timestep of profiles/valu_issue.json beside the static count (cross-check)")
     args = ap.parse_args()
     flags = args.flags.split()
     blocks = loop_blocks(listing(args.unit, flags), args.kernel)
@@ -210,6 +212,16 @@ def main():
         top = ", ".join("{0} {1:.0f}".format(k, v) for k, v in mnem[(u, cls)].most_common(6) if v > 0)
         out.append("    {0:<5} {1:<72} {2:7.1f}  {3:5.1f} %{4}   [{5}]".format(u, cls, n, 100.0 * n / valu if u == "VALU" else 0.0,
                    " of VALU" if u == "VALU" else "        ", top))
+    if args.pmc:
+        import json
+        key, nw, steps = args.pmc.split(",")
+        rec = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))[key]
+        meas = rec["classes"]["VALU"] / (rec["chains"] * int(nw) * int(steps))
+        f64 = (rec["classes"]["ADD_F64"] + rec["classes"]["MUL_F64"] + rec["classes"]["FMA_F64"]) / (rec["chains"] * int(nw) * int(steps))
+        out.append("")
+        out.append("cross-check, rocprofv3 PMC of the production kernel (profiles/valu_issue.json:{0}): SQ_INSTS_VALU {1:.1f} per wave-timestep, "
+                   "fp64 add/mul/fma {2:.1f} -- static count above: {3:.1f} / {4:.1f}".format(
+                       key, meas, f64, valu, sum(n for (u, c), n in tot.items() if c.startswith("fp64 add"))))
     if args.blocks:
         out.append("")
         out.append("blocks (label, instructions, weight, why):")
