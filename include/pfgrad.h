@@ -133,7 +133,9 @@ typedef struct pfg_problem {
      * of doubles consumed is data dependent: pfg_result.paris_consumed returns it (-1: the stream was too short, run
      * again with a longer one).  The filter's own draws of a timestep (u, z) precede them in np.random's order, so a
      * caller that reproduces np.random.seed() runs ONE timestep per call (warm start init_x / init_logw / init_stats),
-     * as sgmcmc_ssm_amd.particle_filters does. */
+     * as sgmcmc_ssm_amd.particle_filters does.  A window of several timesteps carries the cursor from one timestep to
+     * the next (PARIS_NO_ACCEPT_REJECT: child i's draw j at timestep t reads double (t N + i) Ntilde + j): given the
+     * concatenation of what the single-timestep calls consumed it repeats them in one launch (with `elementwise`). */
     const double *paris_stream;
     int64_t paris_stream_len;
     int32_t paris_manual_threshold, reserved2;

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                         __syncthreads();                           // woff / wcnt are rewritten by the next round
                     }
                     if (Stot > 0 && !noar && paris_cursor + Stot > cap) paris_overflow = true;
-                    if (Stot > 0 && noar && (long long)N * Nt > cap) paris_overflow = true;
+                    if (Stot > 0 && noar && (long long)(t + 1) * N * Nt > cap) paris_overflow = true;
                     if (!paris_overflow && Stot > 0) {
                         for (int j = 0; j < nchunk; ++j) {
                             const bool pj = (pend >> j) & 1u;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                             const int i = j * NT + tid;
                             const int rank = woff[j * NW + wave] + __popcll(mk & ltmask);
                             qchild[rank] = i;
-                            qum[rank] = (REAL)(noar ? strm[(long long)i * Nt + jt] : strm[paris_cursor + rank]);
+                            qum[rank] = (REAL)(noar ? strm[((long long)t * N + i) * Nt + jt] : strm[paris_cursor + rank]);
                         }
                         if (tid == 0) *qcount = Stot;
                         if (!noar) paris_cursor += Stot;

@@ -911,7 +911,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     // are left (or after max_accept_reject rounds) each of them takes one double, in index order, for its
                     // exact categorical draw.  The rank of a pending child = a workgroup-wide exclusive count of the
                     // pending flags in particle-index order (slot-major: particle k * NT + tid).  accept_reject = False
-                    // (pf.py:226-236): no rounds, child i's draw j takes double i * Ntilde + j.
+                    // (pf.py:226-236): no rounds, child i's draw j at timestep t takes double (t * N + i) * Ntilde + j.
                     const double *__restrict__ const strm = P.paris_stream;
                     const long long cap = P.paris_stream_len;
                     const bool noar = (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) != 0;
@@ -963,14 +963,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     }
                     // the children still pending, in index order: queue position = rank
                     if (S > 0 && !noar && paris_cursor + S > cap) paris_overflow = true;
-                    if (S > 0 && noar && (long long)N * Nt > cap) paris_overflow = true;
+                    if (S > 0 && noar && (long long)(t + 1) * N * Nt > cap) paris_overflow = true;
                     if (!paris_overflow) {
 #pragma unroll
                         for (int k = 0; k < PPT; ++k) {
                             if (!pend[k]) continue;
                             const int i = k * NT + tid;
                             queue[rank[k]] = i;
-                            const double um = noar ? strm[(long long)i * Nt + j] : strm[paris_cursor + rank[k]];
+                            const double um = noar ? strm[((long long)t * N + i) * Nt + j] : strm[paris_cursor + rank[k]];
                             nxt[(size_t)NS * NLS + i] = (REAL)um;
                         }
                         if (tid == 0) *qcount = S;

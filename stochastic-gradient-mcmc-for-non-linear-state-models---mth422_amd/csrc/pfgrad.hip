@@ -631,7 +631,6 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     return fail(ctx, PFG_ERR_INVALID, id + "paris_stream_len and paris_manual_threshold must be >= 0");
                 if (q.N > pfg::MEM_MAX_N)
                     return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'paris' is implemented for N <= 16384");
-                if (q.elementwise) return fail(ctx, PFG_ERR_UNSUPPORTED, id + "paris_stream does not combine with elementwise statistics");
             } else if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u)))) {
                 return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools or paris_stream");
             }

@@ -262,7 +262,7 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
         mar = kwargs.pop("max_accept_reject", None)
         paris_kw["Ntilde"] = int(kwargs.pop("Ntilde", 2))
         pools = [kwargs.pop(k, None) for k in ("paris_idx_u", "paris_acc_u", "paris_man_u")]
-        if rng == "replay" and pools[2] is None and int(N) <= 16384 and stat in ("score", "suff") and dtype == "f64":
+        if rng == "replay" and pools[2] is None and int(N) <= 16384 and stat in ("score", "suff", "none") and dtype == "f64":
             q = dict(model=model, kernel=kernel, smoother="paris", stat=stat, dtype=dtype, rng="replay", N=int(N),
                      t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=1.0, Ntilde=paris_kw["Ntilde"],
                      prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
@@ -348,6 +348,7 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
     all_x, all_lw, all_st, all_ll = [x.copy()], [logw.copy()], [stats[:, :h].copy()], [0.0]
     ll, mean_stat = 0.0, np.zeros(h)
     pflags = flags | (0 if accept_reject else _capi.FLAG_PARIS_NO_ACCEPT_REJECT)
+    us, zs, consumed = [], [], []       # the draws of this window, for a second launch on the same numbers (elementwise pass)
     for t in range(T):
         u = rs.random_sample(N)
         z = rs.normal(size=N)
@@ -370,6 +371,7 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
             M *= 4                      # the block ran out: the same step again with a longer one
         if used > 0:
             rs.random_sample(used)      # the generator now stands where the reference's stands
+        us.append(u); zs.append(z); consumed.append(block[:used])
         _paris_block_hint[(N, Nt)] = max(int(used), 1)
         x, logw = o["x_t"], o["log_weights"]
         stats = np.zeros((N, _capi.STAT_DIM[q["model"]]))
@@ -379,7 +381,19 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
         all_x.append(x.copy()); all_lw.append(logw.copy()); all_st.append(stats[:, :h].copy()); all_ll.append(ll)
     return dict(mean_stat=np.asarray(mean_stat)[:h], loglik=ll, x_t=x, log_weights=logw, statistics=stats[:, :h],
                 all_x_t=np.array(all_x), all_log_weights=np.array(all_lw), all_statistics=np.array(all_st),
-                all_loglikelihood_estimate=np.array(all_ll))
+                all_loglikelihood_estimate=np.array(all_ll),
+                _draws=dict(z0=z0, u=np.array(us).reshape(T, N), z=np.array(zs).reshape(T, N),
+                            paris_stream=np.concatenate(consumed) if consumed else np.zeros(0), flags=pflags,
+                            max_accept_reject=mar, paris_manual_threshold=mst))
+
+
+def paris_replay_again(q):
+    """The problem dict that re-runs a window _paris_replay_window has run, in ONE launch on the same random
+    numbers: the filter's z0 / u / z and, as paris_stream, exactly the uniforms the backward sampling consumed
+    (the kernel carries its stream cursor across timesteps).  Same ancestors, same parents, same numbers; the
+    caller adds what it wants recorded on top (Helper.pf_latent_var_distr: the elementwise statistics)."""
+    d = q["_result"]["_draws"]
+    return dict({k: v for k, v in q.items() if k != "_result"}, **d)
 
 
 def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,

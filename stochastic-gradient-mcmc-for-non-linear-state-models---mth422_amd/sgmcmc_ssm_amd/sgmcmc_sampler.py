@@ -189,7 +189,16 @@ class PFHelper(object):
         kwargs.pop("tqdm", None)
         q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
                             pf, N, kernel, forward_message, stat="none", **kwargs)
-        o = _capi.default_context().run_batch([q], want_elementwise=True)[0]
+        if "_result" in q:
+            # pf='paris' in np.random's order: the window has just run step by step (that fixed how many uniforms
+            # each backward sampling consumed and left the generator where the reference leaves it); the same
+            # window once more in one launch, on the same numbers, with the elementwise pass behind it
+            q2 = _pf.paris_replay_again(q)
+            o = _capi.default_context().run_batch([q2], want_elementwise=True)[0]
+            if o["paris_consumed"] != q2["paris_stream"].shape[0]:
+                raise RuntimeError("PaRIS replay consumed {0} of {1} uniforms".format(o["paris_consumed"], q2["paris_stream"].shape[0]))
+        else:
+            o = _capi.default_context().run_batch([q], want_elementwise=True)[0]
         _pf._recycle_streams([q])
         avg = np.reshape(o["ew_mean"], (-1, 3))
         if self.model == "garch" and squared:

@@ -37,7 +37,9 @@ def test_oracle_elementwise_matches_reference(golden_latent):
 @pytest.mark.gpu
 def test_latent_var_distr_gpu_matches_reference(golden_latent):
     """Helper.pf_latent_var_distr through the device elementwise pass (pfg_problem.elementwise) against
-    the reference's own outputs on identical seeds: poyiadjis_N, nemeth and poyiadjis_N2 replay NumPy's stream."""
+    the reference's own outputs on identical seeds: poyiadjis_N, nemeth, poyiadjis_N2 and paris (np.random's
+    order: the window runs step by step to fix the data-dependent consumption, then once more in one launch on the
+    same numbers with the elementwise pass) replay NumPy's stream and leave the generator where the reference does."""
     from sgmcmc_ssm_amd.models.svm import SVMHelper
     from sgmcmc_ssm_amd.models.garch import GARCHHelper
     from sgmcmc_ssm_amd.models.lgssm import LGSSMHelper
@@ -45,8 +47,6 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
     g = golden_latent
     n = 0
     for m in g.meta:
-        if m["pf"] == "paris":          # data-dependent number of draws: pool parity + statistics below
-            continue
         model = m["model"]
         p = default_params(model)
         fm = None if model == "garch" else dict(log_constant=0.0, mean_precision=np.zeros(1),
@@ -58,6 +58,12 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
                                             N=m["N"], kernel=m["kernel"])
         np.testing.assert_allclose(xm, g.get(m["key"], "x_mean"), rtol=1e-9, atol=1e-9, err_msg=str(m))
         np.testing.assert_allclose(xc, g.get(m["key"], "x_cov"), rtol=1e-8, atol=1e-9)
+        if m["pf"] == "paris":
+            # the generator stands where the reference's stands: the oracle (bit-exact to the reference, see
+            # test_oracle_elementwise_matches_reference) draws the same next number
+            rng = np.random.RandomState(m["seed"])
+            po.latent_var_distr(model, g.get(m["key"], "theta"), g.get(m["key"], "y"), m["N"], rng=rng, **_kw(m))
+            assert np.random.random_sample() == rng.random_sample(), m
         if model == "garch":
             np.random.seed(m["seed"])
             xm, xc = helper.pf_latent_var_distr(observations=g.get(m["key"], "y").reshape(-1, 1), parameters=p,
@@ -65,7 +71,7 @@ def test_latent_var_distr_gpu_matches_reference(golden_latent):
                                                 pf=m["pf"], kernel=m["kernel"], squared=True)
             np.testing.assert_allclose(xm, g.get(m["key"], "x_mean_sq"), rtol=1e-9, atol=1e-9)
         n += 1
-    assert n == 12
+    assert n == 16
     with pytest.raises(ValueError):
         helper.pf_latent_var_distr(observations=np.zeros((4, 1)), parameters=p, lag=0)
     with pytest.raises(ValueError):
@@ -128,9 +134,35 @@ def test_elementwise_pass_vs_oracle_paris(model, kernel, N, Ntilde, R):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,N,T", [("svm", 200, 25), ("garch", 1500, 12), ("lgssm", 64, 30)])
+def test_latent_var_distr_paris_no_accept_reject_seed_for_seed(model, N, T):
+    """paris_smoother(accept_reject=False) (pf.py:226-236) with elementwise statistics, against the oracle on the
+    same seed: in one launch the kernel addresses the stream as (t * N + i) * Ntilde + j.  N = 1500: large-N kernel."""
+    from sgmcmc_ssm_amd.models.svm import SVMHelper
+    from sgmcmc_ssm_amd.models.garch import GARCHHelper
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMHelper
+    np.random.seed(3)
+    p = default_params(model)
+    y = GEN[model](T=T, parameters=p)["observations"]
+    fm = None if model == "garch" else dict(log_constant=0.0, mean_precision=np.zeros(1), precision=np.eye(1) / 1.7)
+    helper = dict(svm=SVMHelper, garch=GARCHHelper, lgssm=LGSSMHelper)[model](n=1, m=1, forward_message=fm)
+    np.random.seed(77)
+    xm, xc = helper.pf_latent_var_distr(observations=y, parameters=p, pf="paris", N=N, accept_reject=False,
+                                        subsequence_start=2, subsequence_end=T - 3)
+    rng = np.random.RandomState(77)
+    pm, pv, _ = helper._prior_x(fm, p)
+    kw = dict(kernel=po.DEFAULT_KERNEL[model], pf="paris", t1=2, tL=T - 3, accept_reject=False,
+              prior_mean=float(np.asarray(pm).reshape(-1)[0]), prior_var=float(np.asarray(pv).reshape(-1)[0]))
+    rm, rc = po.latent_var_distr(model, p.theta(), y.reshape(-1), N, rng=rng, **kw)
+    np.testing.assert_allclose(xm, rm, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(xc, rc, rtol=1e-8, atol=1e-9)
+    assert np.random.random_sample() == rng.random_sample()
+
+
+@pytest.mark.gpu
 def test_latent_var_distr_paris_statistics(golden_latent):
-    """Through the Helper API pf='paris' runs on the device generator: its smoothed means agree with the
-    reference's (different random numbers) within Monte-Carlo error, and with the O(N) smoother's."""
+    """pf='paris' on the device generator (rng='device'): its smoothed means agree with the reference's
+    (different random numbers) within Monte-Carlo error, and with the O(N) smoother's."""
     from sgmcmc_ssm_amd.models.svm import SVMHelper
     g = golden_latent
     m = [q for q in g.meta if q["pf"] == "paris" and q["model"] == "svm"][0]
@@ -139,7 +171,7 @@ def test_latent_var_distr_paris_statistics(golden_latent):
     helper = SVMHelper(n=1, m=1, forward_message=fm)
     y = g.get(m["key"], "y").reshape(-1, 1)
     np.random.seed(1)
-    xm, xc = helper.pf_latent_var_distr(observations=y, parameters=p, pf="paris", N=4000)
+    xm, xc = helper.pf_latent_var_distr(observations=y, parameters=p, pf="paris", N=4000, rng="device")
     np.random.seed(2)
     xm2, xc2 = helper.pf_latent_var_distr(observations=y, parameters=p, pf="poyiadjis_N", N=4000)
     assert xm.shape == (y.shape[0], 1) and np.all(xc > 0)
