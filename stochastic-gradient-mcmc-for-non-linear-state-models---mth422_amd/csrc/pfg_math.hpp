@@ -117,7 +117,8 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 // (ms per bench launch, xoshiro / jsf32: SVM 46.8 / 45.5, N = 4000 12.23 / 11.92, GARCH windows 2.71 / 2.67, one wave
 // 1.73 / 1.70, N = 10000 6.79 / 6.70; profiles/r03_ab_jsf32.txt).  The draws are inputs of the filter; their
 // distribution is tested on what the kernels record (tests/test_gpu_device_replay.py::test_recorded_draws_are_standard,
-// tests/test_gpu_ensemble.py::test_device_generator_normals_and_uniform_streams).
+// tests/test_gpu_ensemble.py::test_device_generator_normals_and_uniform_streams, ::test_device_generator_large_sample;
+// 2e9 draws: profiles/r03_generator_tails.txt).
 // ------------------------------------------------------------------------------------
 struct LaneRng {
     uint32_t s0, s1, s2, s3;

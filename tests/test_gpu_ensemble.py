@@ -386,3 +386,24 @@ def test_full_size_workload_device_vs_replay():
     assert np.all(zscore < 5.0), (zscore, got.mean(axis=0), ref.mean(axis=0))
     ratio = got.std(axis=0) / ref.std(axis=0)
     assert np.all((ratio > 0.6) & (ratio < 1.6)), ratio
+
+
+def test_device_generator_large_sample():
+    """The inputs of the filter as the bench instantiation draws them, 2.6e8 of each kind reduced on the device
+    (tools/generator_tails.py; profiles/r03_generator_tails.txt holds the 2e9-draw run): moments, two-sided tails out to
+    5.5 sigma against N(0,1) within 5 Poisson standard errors, chi-square of 512 equiprobable bins, of the words' top
+    12 and low 8 bits, no correlation between neighbouring chains or between a child's word and its normal."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import generator_tails
+    o = generator_tails.collect(chains=128, launches=2)
+    assert o["variant"] == "wg256x4s" and o["draws"] == 256 * 10 ** 6
+    assert all(abs(o["moments"][k]) < 5 for k in ("z_mean", "z_var", "z_third", "z_fourth")), o["moments"]
+    for t in o["tails"]:
+        if t["expected"] >= 5:
+            assert abs(t["z"]) < 5, t
+    assert o["max_abs_z"] < 6.8
+    for k in ("chi2_normal_equiprobable", "chi2_words_top12", "chi2_words_low8"):
+        assert o[k]["p"] > 1e-5, (k, o[k])
+    assert abs(o["corr_neighbouring_chains"]["z"]) < 5 and abs(o["corr_word_normal"]["z"]) < 5
