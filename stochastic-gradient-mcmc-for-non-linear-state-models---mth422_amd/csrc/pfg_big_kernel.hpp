@@ -59,8 +59,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     const double lam_d = is_filter ? 0.0 : P.lambduh;
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
-    const double *__restrict__ const yv = P.y;
-    const double *__restrict__ const wv = P.weights;
+    const gptr<const double> yv = global_ptr(P.y);
+    const gptr<const double> wv = global_ptr(P.weights);
 
     double *cdf = reinterpret_cast<double *>(smem);                 // [NP2 + NP2/32] physical
     double *red_scan = cdf + (NP2 + NP2 / 32);                      // [CH2*NW] (chunk, wave) totals of the weights
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
     double *tabmem = red_W + 8;
 
     constexpr int REC = mem_rec_len<MODEL, REAL>();
-    REAL *lwg = reinterpret_cast<REAL *>(P.scratch);                // [N]
-    REAL *cur = reinterpret_cast<REAL *>((reinterpret_cast<uintptr_t>(lwg + N) + 15) & ~(uintptr_t)15);   // [N][REC]
-    REAL *nxt = cur + (size_t)REC * N;
+    gptr<REAL> lwg = global_ptr(reinterpret_cast<REAL *>(P.scratch));    // [N]
+    gptr<REAL> cur = (gptr<REAL>)(((uintptr_t)(lwg + N) + 15) & ~(uintptr_t)15);   // [N][REC]
+    gptr<REAL> nxt = cur + (size_t)REC * N;
 
     Math<REAL, true> mth;
     mth.t.e2 = tabmem;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_big_kernel(const pfg_dev_problem *_
         };
         if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
         else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
-        { REAL *tmp = cur; cur = nxt; nxt = tmp; }
+        { gptr<REAL> tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
         // children (global stores) become visible to the next step's gathers at its barriers
     }

@@ -12,8 +12,13 @@
 // 53-bit double (a >> 5, b >> 6), Marsaglia's polar method with the second variate cached.
 // Host-only translation unit, compiled with -ffp-contract=off (x1*x1 + x2*x2 must not be fused).
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <pthread.h>
+#include <sched.h>
 #include <cmath>
 #include <immintrin.h>
+#include <memory>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -169,6 +174,66 @@ inline void stream_copy(bool avx2, double *dst, const double *src, size_t n) {
     if (avx2) stream_copy_avx2(dst, src, n); else std::memcpy(dst, src, n * sizeof(double));
 }
 
+// ---- where the transform workers run -------------------------------------------------------------------------
+// The accepted attempts travel from the sequential stage to a worker through cache lines; when the scheduler puts the
+// worker on the other socket (the GPU box's host: 2 x 64 cores, cgroup quota, no cpuset) every line of the ring costs a
+// cross-socket transfer and the SEQUENTIAL stage slows down (measured, T = N = 1000, two threads: 2.9 ms unplaced,
+// 2.0-2.2 ms with the worker on a core that shares the caller's L3; one thread: 3.8 ms).  So the short-lived worker
+// threads -- never the caller's thread -- are placed on cores that share the L3 of the CPU the caller is running on
+// right now: one hardware thread per core, the caller's own core left out, only CPUs the process may use.
+// PFGRAD_RNG_PIN=0 leaves placement to the scheduler.
+std::vector<int> parse_cpu_list(const char *path) {
+    std::vector<int> out;
+    FILE *f = std::fopen(path, "r");
+    if (!f) return out;
+    char buf[4096];
+    if (std::fgets(buf, sizeof buf, f)) {
+        const char *p = buf;
+        while (*p) {
+            char *e;
+            const long a = std::strtol(p, &e, 10);
+            if (e == p) break;
+            long b = a;
+            p = e;
+            if (*p == '-') { b = std::strtol(p + 1, &e, 10); p = e; }
+            for (long c = a; c <= b && out.size() < 4096; ++c) out.push_back((int)c);
+            if (*p == ',') ++p; else break;
+        }
+    }
+    std::fclose(f);
+    return out;
+}
+
+std::vector<int> cores_near(int cpu) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, std::vector<int>>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &c : cache) if (c.first == cpu) return c.second;
+    std::vector<int> out;
+    char path[128];
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (cpu >= 0 && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        const std::vector<int> l3 = parse_cpu_list(path);
+        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        const std::vector<int> mine = parse_cpu_list(path);
+        for (int c : l3) {
+            if (c < 0 || c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
+            bool own = c == cpu;
+            for (int m : mine) own = own || m == c;
+            if (own) continue;
+            std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            const std::vector<int> sib = parse_cpu_list(path);
+            bool first = true;                            // one hardware thread per core: the lowest-numbered sibling
+            for (int sc : sib) first = first && sc >= c;
+            if (first) out.push_back(c);
+        }
+    }
+    if (cache.size() < 512) cache.emplace_back(cpu, out);
+    return out;
+}
+
 }  // namespace
 
 extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, int N, int T,
@@ -191,8 +256,9 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
     // The accepted attempts of a SLICE of rows wait in a small ring of buffers (cache resident) for their
     // transform -- sqrt, log, divide per pair with the host libm NumPy calls -- which runs on worker threads
     // behind the sequential word / acceptance loop (threads = 1: on this thread, slice by slice).
-    // Measured on the MI355X box's host (EPYC 9575F), T = N = 1000: sequential stage 1.5 ms, transforms 2.2 ms.
-    int nt = threads > 0 ? threads : 2;
+    // Measured on the MI355X box's host (EPYC 9575F), T = N = 1000 (profiles/r03_host_generator.txt): sequential stage
+    // 1.9 ms (MT19937 blocks 0.70, uniforms 0.27, attempts 0.50, acceptance 0.25), transforms 1.9 ms: two workers keep up.
+    int nt = threads > 0 ? threads : 3;
     if (nt > 16) nt = 16;
     if (total < 200000) nt = 1;
     const int W = nt - 1;                                       // transform workers
@@ -202,12 +268,20 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
     constexpr int RING = 8;
     std::vector<double> ring_mem;
     try { ring_mem.resize((size_t)RING * 3 * cap); } catch (...) { return PFG_ERR_NOMEM; }
-    struct Slot { std::atomic<long> tag{0}; size_t q0 = 0, n = 0; };      // tag = slice + 1 while that slice waits in the buffer, 0 = free
-    Slot slots[RING];
-    std::atomic<long> n_slices{-1};                             // set when the main loop is done
-    auto seg = [&](long j, int which) -> double * { return ring_mem.data() + ((size_t)(j % RING) * 3 + which) * cap; };
+    // What the workers spin on lives on cache lines of its own: next to the main loop's locals (this stack frame) every
+    // poll of a waiting worker would pull the line the sequential stage is writing to (measured on the GPU box's host,
+    // two threads: the sequential stage 1.9 -> 5.2 ms with the flags on the stack).
+    struct alignas(64) Slot { std::atomic<long> tag{0}; size_t q0 = 0, n = 0; };      // tag = slice + 1 while that slice waits in the buffer, 0 = free
+    struct alignas(64) Shared { Slot slots[RING]; alignas(64) std::atomic<long> n_slices{-1}; char pad[64]; };
+    std::unique_ptr<Shared> shared;
+    try { shared.reset(new Shared); } catch (...) { return PFG_ERR_NOMEM; }
+    Slot *const slots = shared->slots;
+    std::atomic<long> &n_slices = shared->n_slices;             // set when the main loop is done
+    double *const ring = ring_mem.data();
+    auto seg = [ring, cap](long j, int which) -> double * { return ring + ((size_t)(j % RING) * 3 + which) * cap; };
 
-    auto transform_slice = [&](long j) {
+    // (the workers' lambdas hold copies of the constants they need: nothing they read sits in this stack frame)
+    auto transform_slice = [&spill, &spilled, slots, seg, off, total, N, z0, z, avx2](long j) {
         const Slot &sl = slots[j % RING];
         const double *a1 = seg(j, 0), *a2 = seg(j, 1), *a3 = seg(j, 2);
         double tmp[1024];
@@ -228,7 +302,18 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
             q += m;
         }
     };
-    auto worker = [&](int w) {
+    std::vector<int> near;
+    {
+        const char *pin = std::getenv("PFGRAD_RNG_PIN");
+        if (W > 0 && !(pin && pin[0] == '0')) near = cores_near(sched_getcpu());
+    }
+    auto worker = [slots, &n_slices, transform_slice, W, &near](int w) {
+        if ((size_t)w < near.size()) {
+            cpu_set_t cs;
+            CPU_ZERO(&cs);
+            CPU_SET(near[(size_t)w], &cs);
+            pthread_setaffinity_np(pthread_self(), sizeof cs, &cs);        // best effort: a refusal leaves the thread where it is
+        }
         for (long j = w;; j += W) {
             Slot &sl = slots[j % RING];
             unsigned spins = 0;

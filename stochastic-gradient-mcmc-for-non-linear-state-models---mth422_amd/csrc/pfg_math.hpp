@@ -13,6 +13,15 @@ constexpr int WAVE = 64;
 constexpr int MODE_PLAIN = 0, MODE_PARIS = 1, MODE_SYSTEMATIC = 2, MODE_N2 = 3;
 constexpr double LOG_2PI = 1.8378770664093453;   // log(2*pi)
 
+// Pointers that arrive inside a descriptor (pfg_dev_problem) are generic to the compiler, and a generic access is a FLAT
+// instruction: it counts in lgkmcnt as well as vmcnt and may return out of order with LDS operations, so EVERY wait for
+// an LDS result (and every barrier) also waits for the flat loads in flight -- a load issued a timestep ahead is waited
+// for at the next ds_read.  Everything the descriptors point to is device memory (pfg_launch_device's contract): saying
+// so (pointers typed address_space(1)) turns the accesses
+// into global_load / global_store, which only count in vmcnt.
+template <class T> using gptr = T __attribute__((address_space(1))) *;
+template <class T> __device__ __forceinline__ gptr<T> global_ptr(T *p) { return (gptr<T>)p; }
+
 // ------------------------------------------------------------------------------------
 // wave-level primitives (64 lanes) on DPP: row_shr 1,2,4,8 inside 16-lane rows, then
 // row_bcast:15 / row_bcast:31 across rows (gfx9 cross-lane modes; no LDS traffic).

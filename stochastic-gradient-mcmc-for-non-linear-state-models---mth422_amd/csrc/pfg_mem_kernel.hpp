@@ -50,6 +50,22 @@ __device__ __forceinline__ void rec_store(REAL *dst, const REAL *src) {
     for (int v = 0; v < REC * (int)sizeof(REAL) / 16; ++v)
         reinterpret_cast<V *>(dst)[v] = reinterpret_cast<const V *>(src)[v];
 }
+// the same for records in device memory addressed as such (global_load / global_store instead of flat accesses: see
+// global_ptr in pfg_math.hpp)
+template <int REC, typename REAL>
+__device__ __forceinline__ void rec_load(REAL *dst, gptr<const REAL> src) {
+    typedef float V __attribute__((ext_vector_type(4)));      // (a builtin vector: float4's operators want a generic `this`)
+#pragma unroll
+    for (int v = 0; v < REC * (int)sizeof(REAL) / 16; ++v)
+        reinterpret_cast<V *>(dst)[v] = ((gptr<const V>)src)[v];
+}
+template <int REC, typename REAL>
+__device__ __forceinline__ void rec_store(gptr<REAL> dst, const REAL *src) {
+    typedef float V __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int v = 0; v < REC * (int)sizeof(REAL) / 16; ++v)
+        ((gptr<V>)dst)[v] = reinterpret_cast<const V *>(src)[v];
+}
 template <typename REAL, int RNG>
 __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
     const size_t np2 = (size_t)mem_np2(N);

@@ -193,10 +193,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const double lam_d = PFG_EXP_PLAIN ? 1.0 : is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
-    const double *__restrict__ const yv = P.y;
-    const double *__restrict__ const wv = P.weights;
-    const double *__restrict__ const uv = P.u;
-    const double *__restrict__ const zv = P.z;
+    const gptr<const double> yv = global_ptr(P.y);
+    const gptr<const double> wv = global_ptr(P.weights);
+    const gptr<const double> uv = global_ptr(P.u);
+    const gptr<const double> zv = global_ptr(P.z);
 
     constexpr bool FAST = fast_layout(NT, PP);
     constexpr bool TAB = FAST;
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         }
         if (RNG != PFG_RNG_REPLAY && systematic && tid == 0) red_W0[0] = u01_32(rng.next());
         // this step's randomness: REPLAY loads are issued here so that their latency overlaps the
-        // barrier; device draws happen right before their use (keeps register pressure down)
+        // barrier; device draws happen right before their use (keeps register pressure down).  (Loading a timestep
+        // ahead was measured, round 3: a lone window 2.90 -> 2.85 ms, 768 windows 6.85 -> 7.60 ms -- the registers
+        // cost more than the latency; the REPLAY kernel's distance to the device units is its fp64 CDF and search.)
         double uu[PPT];
         REAL zz[PPT];
         if (t < T && RNG == PFG_RNG_REPLAY) {

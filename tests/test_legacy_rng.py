@@ -65,3 +65,25 @@ def test_global_np_random_and_draw_replay_streams():
     rs = np.random.RandomState(6)          # small windows still go through NumPy: same numbers either way
     small = particle_filters.draw_replay_streams(10, 3, rs)
     assert np.array_equal(small[1], numpy_streams(np.random.RandomState(6), 10, 3)[1])
+
+
+def test_worker_placement_leaves_the_caller_alone(monkeypatch):
+    """The transform workers are placed on cores that share the caller's L3 (pfg_legacy_rng.hip: cores_near); the calling
+    thread's own affinity mask is never touched, and PFGRAD_RNG_PIN=0 (placement left to the scheduler) gives the same
+    numbers and the same final state."""
+    import os
+    N, T = 1000, 300
+    before = os.sched_getaffinity(0)
+    outs = []
+    for pin in ("1", "0"):
+        monkeypatch.setenv("PFGRAD_RNG_PIN", pin)
+        rs = np.random.RandomState(77)
+        z0, u, z = np.empty(N), np.empty((T, N)), np.empty((T, N))
+        _capi.legacy_streams(rs, N, T, z0, u, z, threads=4)
+        outs.append((z0, u, z, rs.get_state()))
+        assert os.sched_getaffinity(0) == before
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3][1], b[3][1]) and a[3][2:] == b[3][2:]
+    ref = numpy_streams(np.random.RandomState(77), N, T)
+    assert np.array_equal(ref[2], a[2]) and np.array_equal(ref[1], a[1])
