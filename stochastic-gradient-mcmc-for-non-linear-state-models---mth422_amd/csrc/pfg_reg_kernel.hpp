@@ -217,6 +217,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #define PFG_OPT_SORTED1024 1
 #endif
     constexpr bool SORTED = PFG_OPT_SORTED1024 && BLK && NT == 1024 && PPT == 4 && !systematic && NW > 1;
+    // PRIO: wave issue priority (s_setprio) by phase.  A timestep alternates between phases that are mostly LDS round
+    // trips (E search, F gather) and phases that are mostly VALU work (A-D, G, H); the arbiter of a SIMD otherwise picks
+    // by age.  256 x 4, four workgroups per CU in different phases: the VALU phases at priority 2 and E, F at 0 -- a wave
+    // that is about to wait for the LDS anyway gives way -- 45.6 -> 44.8 ms per bench launch (-1.9 %; the same with 3
+    // instead of 2; nothing if only G, H are raised).  1024 x 4, ONE workgroup per CU whose 16 waves are in the same
+    // phase: the other way round (E, F at 2: the waves that reach the search first get their probes out) 11.26 ->
+    // 11.03 ms (-2.0 %), and +0.4 % with the 256 x 4 setting.  512 x 2 (GARCH) and the one-wave kernels: 0 ... +4 % with
+    // either, so none (profiles/r03_ab_wave_priority.txt).  -DPFG_OPT_PRIO=0 builds without.
+#ifndef PFG_OPT_PRIO
+#define PFG_OPT_PRIO 1
+#endif
+    constexpr int PRIO = !(PFG_OPT_PRIO && BLK && !PP && PPT == 4) ? 0 : (NT == 1024 ? 1 : (NT == 256 ? 2 : 0));
     constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : (PPT == 8 ? 3 : 4)));
     static_assert(PPT <= 16, "LOG_PPT covers 1, 2, 4, 8, 16 particles per thread");
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
@@ -587,6 +599,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         PFG_PH(4)
         block_sync<NW>();                                                       // barrier 3
         PFG_PH(5)
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(2);                           // the LDS-heavy phases E, F: see PRIO
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
         // ---- (E) ancestors: smallest j with cdf[j] > u (searchsorted 'right').  Branch-free:
         // probes past the end read cdf[N-1] (= 1 > u), the final clamp covers rounding.
@@ -736,6 +750,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NLS + anc[k]];
             }
             PFG_PH(7)
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(2);
             if (!PP) block_sync<NW>();                                          // barrier 4 (single buffer)
             PFG_PH(8)
             if (RNG != PFG_RNG_REPLAY) {
