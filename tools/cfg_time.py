@@ -9,7 +9,7 @@ from sgmcmc_ssm_amd.ensemble import ChainEnsemble
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 w = bench.config_workload(cfg)
 C = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else w["chains"]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("CFG_TIME_REPS", "6"))
 ens = ChainEnsemble(w["model"], w["y"], w["p0"], num_chains=C, N=w["N"], kernel=w["kernel"], epsilon=w["epsilon"], prior=w["prior"],
                     subsequence_length=w["S"], buffer_length=w["B"], seed=2024,
                     window_sampling=("device" if w["S"] != -1 and not isinstance(w["y"], list) else "host"))
