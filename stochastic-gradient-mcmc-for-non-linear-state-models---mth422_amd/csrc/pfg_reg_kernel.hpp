@@ -228,11 +228,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
 #ifndef PFG_OPT_PRIO
 #define PFG_OPT_PRIO 1
 #endif
-#ifdef PFG_EXP_PRIO_ALL
-    constexpr int PRIO = BLK ? PFG_EXP_PRIO_ALL : 0;                    // A/B: one setting for every device-generator instantiation
-#else
     constexpr int PRIO = !(PFG_OPT_PRIO && BLK && !PP && PPT == 4) ? 0 : (NT == 1024 ? 1 : (NT == 256 ? 2 : 0));
-#endif
     constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : (PPT == 8 ? 3 : 4)));
     static_assert(PPT <= 16, "LOG_PPT covers 1, 2, 4, 8, 16 particles per thread");
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
