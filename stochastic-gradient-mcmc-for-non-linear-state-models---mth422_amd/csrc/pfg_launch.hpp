@@ -21,8 +21,8 @@ namespace pfg_host {
         }                                                                                                 \
     } while (0)
 
-// traced = the descriptors may carry trace_* / rec_* buffers: the TRACE = true instantiation.  The REPLAY units exist
-// as TRACE = true only (parity path, not the timed one).
+// traced = the descriptors may carry trace_* / rec_* buffers: the TRACE = true instantiation; otherwise the twin with
+// the trace instrumentation compiled out (device generator: what bench.py times; REPLAY: the drop-in Sampler's launch).
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool TRACE>
 int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, pfg::MODE_PLAIN, TRACE>;
@@ -34,9 +34,7 @@ int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
 }
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
-    if constexpr (RNG == PFG_RNG_DEVICE) {
-        if (!traced) return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false>(ctx, n_max, B, dp, st);
-    }
+    if (!traced) return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false>(ctx, n_max, B, dp, st);
     return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, true>(ctx, n_max, B, dp, st);
 }
 template <int MODEL, int KERNEL, typename REAL, int RNG>

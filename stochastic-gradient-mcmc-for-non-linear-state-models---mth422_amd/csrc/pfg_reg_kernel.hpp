@@ -224,11 +224,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     // instead of 2; nothing if only G, H are raised).  1024 x 4, ONE workgroup per CU whose 16 waves are in the same
     // phase: the other way round (E, F at 2: the waves that reach the search first get their probes out) 11.26 ->
     // 11.03 ms (-2.0 %), and +0.4 % with the 256 x 4 setting.  512 x 2 (GARCH) and the one-wave kernels: 0 ... +4 % with
-    // either, so none (profiles/r03_ab_wave_priority.txt).  -DPFG_OPT_PRIO=0 builds without.
+    // either, so none (profiles/r03_ab_wave_priority.txt).  The REPLAY instantiation of 256 x 4 (768 windows, three per CU):
+    // 5.85 -> 5.26 ms with the 256 x 4 setting (5.52 with the opposite one).  -DPFG_OPT_PRIO=0 builds without.
 #ifndef PFG_OPT_PRIO
 #define PFG_OPT_PRIO 1
 #endif
-    constexpr int PRIO = !(PFG_OPT_PRIO && BLK && !PP && PPT == 4) ? 0 : (NT == 1024 ? 1 : (NT == 256 ? 2 : 0));
+    constexpr int PRIO = !(PFG_OPT_PRIO && (BLK || (RNG == PFG_RNG_REPLAY && MODE == MODE_PLAIN)) && !PP && PPT == 4) ? 0 : (NT == 1024 ? 1 : (NT == 256 ? 2 : 0));
     constexpr int LOG_PPT = PPT == 1 ? 0 : (PPT == 2 ? 1 : (PPT == 4 ? 2 : (PPT == 8 ? 3 : 4)));
     static_assert(PPT <= 16, "LOG_PPT covers 1, 2, 4, 8, 16 particles per thread");
     // PP: the cdf is stored at physical index i + (i >> 5) (one pad slot per 32 entries): the
