@@ -371,7 +371,7 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
             M *= 4                      # the block ran out: the same step again with a longer one
         if used > 0:
             rs.random_sample(used)      # the generator now stands where the reference's stands
-        us.append(u); zs.append(z); consumed.append(block[:used])
+        us.append(u); zs.append(z); consumed.append(block[:max(used, 0)].copy())     # (a copy: a view would keep the whole block alive)
         _paris_block_hint[(N, Nt)] = max(int(used), 1)
         x, logw = o["x_t"], o["log_weights"]
         stats = np.zeros((N, _capi.STAT_DIM[q["model"]]))
