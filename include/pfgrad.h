@@ -243,7 +243,7 @@ void *pfg_ctx_stream(pfg_ctx *ctx);
 int pfg_launch_device(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                       int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 /* pfg_launch_device / pfg_launch_device_smoother are the PRODUCTION launches: for the plain (NEMETH / FILTER)
- * LDS-resident kernels of the DEVICE generator they run an instantiation with the trace instrumentation compiled
+ * LDS-resident kernels (DEVICE generator, and REPLAY) they run an instantiation with the trace instrumentation compiled
  * out, which IGNORES the trace_x / trace_logw / trace_stats / trace_ll / trace_anc / rec_* fields of the
  * descriptors (out / final_* / stamps are honoured).  pfg_launch_device_traced runs the twin that honours them
  * (save_all trajectories, recorded generator draws); same arguments as pfg_launch_device_smoother.  Both twins

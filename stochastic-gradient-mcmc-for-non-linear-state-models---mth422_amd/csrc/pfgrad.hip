@@ -140,8 +140,8 @@ int check_combo(pfg_ctx *ctx, int model, int kernel, int dtype, int rng) {
     return PFG_OK;
 }
 
-// traced: the descriptors may carry trace_* / rec_* buffers (the plain LDS-resident device-generator kernels exist
-// as a production twin that ignores them, see pfg_reg_kernel.hpp; every other kernel always honours them)
+// traced: the descriptors may carry trace_* / rec_* buffers (the plain LDS-resident kernels, device generator and
+// REPLAY, exist as a production twin that ignores them, see pfg_reg_kernel.hpp; every other kernel always honours them)
 int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int B,
              const pfg_dev_problem *dp, hipStream_t st, int smoother = PFG_SMOOTHER_NEMETH,
              bool force_mem = false, bool traced = true) {
@@ -169,7 +169,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
                         : v == kVariantParis ? (n_max <= 256 ? "paris256x1" : n_max <= 1024 ? "paris256x4" : "paris_mem1024")
                         : v == kVariantSystematic ? "systematic256x4"
                         : (n_max <= 256 ? "n2_256x1" : n_max <= 1024 ? "n2_256x4" : "n2_mem1024");
-    ctx->last_traced = traced || v < 0 || rng == PFG_RNG_REPLAY;
+    ctx->last_traced = traced || v < 0;
     if (model == PFG_MODEL_SVM) return launch_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
     if (model == PFG_MODEL_GARCH) {
         if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);

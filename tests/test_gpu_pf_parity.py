@@ -475,3 +475,32 @@ def test_theta_grid_replay_f64(ctx):
                 np.testing.assert_allclose(o["log_weights"], g.get(key, "log_weights"), rtol=RTOL, atol=ATOL, err_msg=str(m))
             n += 1
     assert n == len(g.meta) == 76
+
+
+@pytest.mark.parametrize("variant", ["wg256x4s", "wg1024x1", "wg64x2", "wg256x4"])
+@pytest.mark.parametrize("model,kernel", [("svm", "prior"), ("garch", "optimal"), ("lgssm", "optimal")])
+def test_replay_production_twin_equals_traced_twin(ctx, monkeypatch, model, kernel, variant):
+    """The REPLAY kernels have a twin with the trace instrumentation compiled out (what the drop-in Sampler launches, r3);
+    asked for traces the same windows run on the instrumented twin.  Same arithmetic: gradients bitwise equal,
+    log-likelihoods to rounding (flushed per step when traced), and `last_traced` says which one ran."""
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    from test_host_logic import default_params
+    rs = np.random.RandomState(11)
+    theta = default_params(model).theta()
+    N = 100 if variant == "wg64x2" else 1000
+    probs = []
+    for b in range(6):
+        T = 40 + b
+        z0, u, z = po.draw_streams(rs, N, T)
+        probs.append(dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f64", rng="replay", N=N,
+                          t1=3, tL=T - 2, lambduh=1.0 if b % 2 else 0.9, prior_mean=0.0, prior_var=2.0,
+                          y=rs.normal(size=T) * (1.5 if model != "garch" else 0.6), weights=rs.uniform(0.5, 3.0, size=T - 5),
+                          theta=theta, z0=z0, u=u, z=z))
+    a = ctx.run_batch([dict(q) for q in probs], want_final=True)
+    assert ctx.last_variant() == variant and not ctx.last_traced()
+    b = ctx.run_batch([dict(q) for q in probs], want_final=True, want_trace=True)
+    assert ctx.last_variant() == variant and ctx.last_traced()
+    for x, y_ in zip(a, b):
+        assert np.array_equal(x["mean_stat"], y_["mean_stat"]) and np.array_equal(x["x_t"], y_["x_t"])
+        assert np.array_equal(x["log_weights"], y_["log_weights"])
+        assert abs(x["loglik"] - y_["loglik"]) <= 1e-12 * abs(y_["loglik"])
