@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 120          /* 0.1.20 */
+#define PFG_VERSION 121          /* 0.1.21 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -91,6 +91,8 @@ enum pfg_status {
 #define PFG_FLAG_GARCH_STATIONARY_PRIOR 1u /* prior_var = alpha/(1-beta-gamma) (garch/helper.py:324-327) */
 #define PFG_FLAG_PARIS_NO_ACCEPT_REJECT 2u /* paris_smoother(accept_reject=False), pf.py:226-236: every child draws its Ntilde
                                             * parents from the exact backward categorical (REPLAY + paris_stream only) */
+#define PFG_FLAG_PARIS_RAW_STREAM 4u       /* paris_stream is the window's WHOLE np.random stream (see pfg_problem.paris_stream) */
+#define PFG_FLAG_PARIS_RAW_CARRY 8u        /* ... and its first double is the generator's cached Gaussian (has_gauss = 1) */
 
 /* One buffered PF window, host side (all pointers are HOST pointers, C-contiguous f64). */
 typedef struct pfg_problem {
@@ -135,7 +137,17 @@ typedef struct pfg_problem {
      * caller that reproduces np.random.seed() runs ONE timestep per call (warm start init_x / init_logw / init_stats),
      * as sgmcmc_ssm_amd.particle_filters does.  A window of several timesteps carries the cursor from one timestep to
      * the next (PARIS_NO_ACCEPT_REJECT: child i's draw j at timestep t reads double (t N + i) Ntilde + j): given the
-     * concatenation of what the single-timestep calls consumed it repeats them in one launch (with `elementwise`). */
+     * concatenation of what the single-timestep calls consumed it repeats them in one launch (with `elementwise`).
+     * PFG_FLAG_PARIS_RAW_STREAM (N <= 1024): z0 / u / z are NULL and paris_stream holds what RandomState.random_sample
+     * delivers from the generator's current state: the kernel takes EVERYTHING from it in np.random's order -- N normals
+     * for x0, then per timestep N uniforms, N normals and the backward sampling's uniforms -- so a whole window is one
+     * launch.  The normals are NumPy's legacy Gaussians (Marsaglia's polar method on pairs of doubles, second variate of
+     * a pair cached for the next draw): acceptance is exact fp64 arithmetic, so the consumption is the reference's to
+     * the double; the values go through the device's log (<= 1 ulp from the host libm's; REPLAY tolerance).  With
+     * PFG_FLAG_PARIS_RAW_CARRY paris_stream[0] is the generator's pending cached Gaussian and the doubles start at [1].
+     * pfg_result.paris_consumed counts the doubles taken (incl. that slot); pfg_result.paris_carry_back != 0: a cached
+     * Gaussian is pending at the end, the second variate of the pair of doubles that starts paris_carry_back doubles
+     * before the end of the consumption (the caller recomputes it with its own libm and hands the generator on). */
     const double *paris_stream;
     int64_t paris_stream_len;
     int32_t paris_manual_threshold, reserved2;
@@ -157,7 +169,7 @@ typedef struct pfg_result {
     double *trace_stats;/* [(T+1)*N*h]  = 'all_statistics' (NEMETH)     */
     double *trace_ll;   /* [T+1]        = 'all_loglikelihood_estimate'  */
     int32_t status;
-    int32_t reserved;
+    int32_t paris_carry_back;   /* PFG_FLAG_PARIS_RAW_STREAM: see pfg_problem.paris_stream; else 0 */
     int32_t *trace_anc; /* [T*N] ancestor index of every particle at every step (with trace_x):
                            the genealogy, from which smoothed marginals are traced back */
     double pred[PFG_MAX_PRED]; /* PFG_STAT_PREDICTIVE: out['statistics'][k] of the reference */
@@ -211,7 +223,7 @@ typedef struct pfg_dev_problem {
                                 every child and draw: the structure the elementwise statistics are carried through */
     const double *paris_stream;      /* see pfg_problem.paris_stream */
     int64_t paris_stream_len;
-    int64_t *paris_consumed;         /* [1] or NULL */
+    int64_t *paris_consumed;         /* [2] or NULL: doubles consumed (-1: stream too short), carry-back distance */
     int32_t paris_manual_threshold, reserved4;
     uint64_t *stamps;        /* [PFG_STAMP_WORDS] or NULL (measurement): wave 0 of the workgroup writes
                                 s_memtime / s_memrealtime (100 MHz) at kernel start [0],[1] and end [2],[3]

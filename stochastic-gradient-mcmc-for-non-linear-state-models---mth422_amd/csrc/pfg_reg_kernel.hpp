@@ -304,6 +304,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     };
 
     REAL lw[PPT];
+    long long paris_cursor = 0;            // PaRIS in the reference's stream order: doubles of P.paris_stream consumed so far
+    bool paris_overflow = false;           // ... and whether the stream ran out (the host retries with a longer one)
+    // RAW (PFG_FLAG_PARIS_RAW_STREAM, PaRIS REPLAY): P.paris_stream is the window's WHOLE np.random stream as doubles
+    // (RandomState.random_sample): the kernel takes from it, in np.random's order, the N resampling uniforms of a timestep,
+    // its N normals and the backward sampling's uniforms -- one launch for a window whose consumption is data dependent.
+    // The normals are NumPy's legacy Gaussians (legacy_gauss: Marsaglia's polar method on pairs of doubles, the second
+    // variate of a pair cached for the next call): accept / reject is exact fp64 arithmetic (no contraction in the REPLAY
+    // units), so the CONSUMPTION is the reference's to the double; the values go through this device's log (<= 1 ulp from
+    // the host libm's), within the REPLAY tolerance.
+    constexpr bool RAWCAP = MODE == MODE_PARIS && RNG == PFG_RNG_REPLAY;
+    const bool raw = RAWCAP && (P.flags & PFG_FLAG_PARIS_RAW_STREAM) != 0 && P.paris_stream != nullptr;
+    bool carry_has = false;                // a cached second variate is pending (workgroup-uniform); its value sits in red_W0[1]
+    double *const zbuf = reinterpret_cast<double *>(paris_queue);          // [N] normals of the current call (queue scratch is free then)
+    long long *const raw_slots = reinterpret_cast<long long *>(red_W0 + 2);  // [0] cut-off attempt of a call, [1] stream position of the cached pair
+    [[maybe_unused]] auto legacy_normals = [&]() {
+        const gptr<const double> strm = global_ptr(P.paris_stream);
+        const long long cap = P.paris_stream_len;
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        int *const wc = reinterpret_cast<int *>(red_scan);                 // [PPT][NW] accepted attempts per (slot, wave)
+        const int produced0 = carry_has ? 1 : 0;
+        __syncthreads();                                                   // queue scratch / red_scan of the previous phase are done with
+        if (carry_has && tid == 0) zbuf[0] = red_W0[1];
+        const int need = (N - produced0 + 1) >> 1;                         // pairs to accept
+        const long long base = paris_cursor;
+        int acc = 0;
+        for (int round = 0; acc < need && !paris_overflow; ++round) {
+            double x1[PPT], x2[PPT], r2[PPT];
+            bool fl[PPT];
+            int rank[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const long long p = base + 2 * ((long long)round * (NT * PPT) + k * NT + tid);
+                const bool in = p + 1 < cap;
+                const double d0 = in ? strm[p] : 0.5, d1 = in ? strm[p + 1] : 0.5;
+                x1[k] = 2.0 * d0 - 1.0;
+                x2[k] = 2.0 * d1 - 1.0;
+                r2[k] = x1[k] * x1[k] + x2[k] * x2[k];
+                fl[k] = in && !(r2[k] >= 1.0 || r2[k] == 0.0);
+                const unsigned long long mk = __ballot(fl[k]);
+                rank[k] = __popcll(mk & ltm);
+                if (lane == 0) wc[k * NW + wave] = __popcll(mk);
+            }
+            __syncthreads();
+            int S = 0;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    if (w == wave) rank[k] += S;
+                    S += wc[k * NW + w];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int q = acc + rank[k];
+                if (fl[k] && q < need) {
+                    const double f = sqrt(-2.0 * log(r2[k]) / r2[k]);
+                    const int i0 = produced0 + 2 * q;
+                    zbuf[i0] = f * x2[k];                                  // returned by this call of legacy_gauss
+                    const long long j = (long long)round * (NT * PPT) + k * NT + tid;
+                    if (i0 + 1 < N) zbuf[i0 + 1] = f * x1[k];              // the cached one, returned by the next call
+                    else { red_W0[1] = f * x1[k]; raw_slots[1] = base + 2 * j; }
+                    if (q == need - 1) raw_slots[0] = j;
+                }
+            }
+            acc += S;
+            if (acc < need && base + 2 * ((long long)(round + 1) * (NT * PPT)) + 1 >= cap) paris_overflow = true;
+            __syncthreads();
+        }
+        if (need > 0 && !paris_overflow) paris_cursor = base + 2 * (raw_slots[0] + 1);
+        carry_has = ((N - produced0) & 1) != 0;
+    };
+    if (RAWCAP && raw && (P.flags & PFG_FLAG_PARIS_RAW_CARRY)) {          // the generator came with a cached Gaussian: stream[0]
+        carry_has = true;
+        if (tid == 0) red_W0[1] = P.paris_stream[0];
+        paris_cursor = 1;
+    }
     // ---- x0 (kernels.py:83-100, garch/kernels.py:7-18) or warm start ------------------
     {
         double pv = P.prior_var;
@@ -312,6 +389,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         const double sd = sqrt(pv);
         REAL z0[PPT];
         if (RNG == PFG_RNG_DEVICE) draw_normals(z0);
+        if constexpr (RAWCAP) { if (raw && !P.init_x) legacy_normals(); }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = k * NT + tid;
@@ -331,7 +409,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         for (int h = 0; h < H; ++h) s[h] = (REAL)P.init_stats[(size_t)i * H + h];
                     }
                 } else {
-                    const double z = (RNG == PFG_RNG_REPLAY) ? P.z0[i] : (double)z0[k];
+                    const double z = (RNG == PFG_RNG_REPLAY) ? ((RAWCAP && raw) ? zbuf[i] : P.z0[i]) : (double)z0[k];
                     x[0] = (REAL)(P.prior_mean + sd * z);
                     if (RNG == PFG_RNG_DEVICE && PFG_TR(P.trace_x) && P.rec_z0) P.rec_z0[i] = z;
                 }
@@ -353,8 +431,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     }
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
-    long long paris_cursor = 0;            // PaRIS in the reference's stream order: doubles of P.paris_stream consumed so far
-    bool paris_overflow = false;           // ... and whether the stream ran out (the host retries with a longer one)
     constexpr bool LAZYLL = PFG_OPT_LAZYLL && TAB && sizeof(REAL) == 8;
     double ll_W = 1.0, ll_w = 0.0;          // LAZYLL: lane t % 64 of wave 0 holds step t's (W, w, m)
     float ll_m = 0.0f;
@@ -375,6 +451,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const int last = N - 1;
 
     for (int t = 0; t <= T; ++t) {
+        [[maybe_unused]] double uu_raw[PPT];
+        [[maybe_unused]] REAL zz_raw[PPT];
+        if constexpr (RAWCAP) {
+            if (raw && t < T) {
+                // np.random's order within a timestep: N uniforms (np.random.choice), N normals (Kernel.rv), then the
+                // backward sampling's draws (at the end of this iteration)
+                const gptr<const double> strm = global_ptr(P.paris_stream);
+                if (paris_cursor + N > P.paris_stream_len) paris_overflow = true;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) uu_raw[k] = paris_overflow ? 0.5 : strm[paris_cursor + own[k]];
+                if (!paris_overflow) paris_cursor += N;
+                legacy_normals();
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) zz_raw[k] = (REAL)zbuf[own[k]];
+            }
+        }
         // ---- (A) block max of the current log weights  (log_normalize, pf.py:374-377) ----
         float ml = (float)lw[0];
 #pragma unroll
@@ -450,10 +542,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         double uu[PPT];
         REAL zz[PPT];
         if (t < T && RNG == PFG_RNG_REPLAY) {
+            if (RAWCAP && raw) {
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                uu[k] = uv[(size_t)t * N + own[k]];
-                zz[k] = (REAL)zv[(size_t)t * N + own[k]];
+                for (int k = 0; k < PPT; ++k) { uu[k] = uu_raw[k]; zz[k] = zz_raw[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    uu[k] = uv[(size_t)t * N + own[k]];
+                    zz[k] = (REAL)zv[(size_t)t * N + own[k]];
+                }
             }
         }
         PFG_PH(2)
@@ -930,8 +1027,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     // are left (or after max_accept_reject rounds) each of them takes one double, in index order, for its
                     // exact categorical draw.  The rank of a pending child = a workgroup-wide exclusive count of the
                     // pending flags in particle-index order (slot-major: particle k * NT + tid).  accept_reject = False
-                    // (pf.py:226-236): no rounds, child i's draw j at timestep t takes double (t * N + i) * Ntilde + j.
-                    const double *__restrict__ const strm = P.paris_stream;
+                    // (pf.py:226-236): no rounds, child i's draw j takes double i * Ntilde + j of the timestep's N * Ntilde (the cursor
+                    // moves on by N * Ntilde behind the last draw).
+                    const gptr<const double> strm = global_ptr(P.paris_stream);       // global_load: see global_ptr
                     const long long cap = P.paris_stream_len;
                     const bool noar = (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) != 0;
                     const int mthr = P.paris_manual_threshold;
@@ -960,36 +1058,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         __syncthreads();                                // wcnt is rewritten by the next round
                         if (S == 0 || noar || S <= mthr || round >= R || paris_overflow) break;
                         if (paris_cursor + 2ll * S > cap) { paris_overflow = true; break; }
+                        // A round is a dependent chain: HBM latency of the two uniforms, ten LDS probes, gather, exp.  All four
+                        // slots of a thread walk it TOGETHER (loads first, the searches level by level, branch-free; a slot
+                        // that is not pending searches with u = -1 and ends at parent 0): one after the other, behind an
+                        // `if (!pend[k]) continue`, a round cost 8 us.
+                        double u1v[PPT], u2v[PPT];
 #pragma unroll
                         for (int k = 0; k < PPT; ++k) {
-                            if (!pend[k]) continue;
-                            const double u1 = strm[paris_cursor + rank[k]], u2 = strm[paris_cursor + S + rank[k]];
-                            int I = 0;
+                            u1v[k] = pend[k] ? strm[paris_cursor + rank[k]] : -1.0;
+                            u2v[k] = pend[k] ? strm[paris_cursor + S + rank[k]] : 2.0;
+                        }
+                        int Iv[PPT];
 #pragma unroll
-                            for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
-                                const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
-                                I += (cdf[I + probe] <= u1) ? step + (step >> 5) : 0;
-                            }
+                        for (int k = 0; k < PPT; ++k) Iv[k] = 0;
+#pragma unroll
+                        for (int step = (NT * PPT) >> 1; step >= 1; step >>= 1) {
+                            const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+#pragma unroll
+                            for (int k = 0; k < PPT; ++k) Iv[k] += (cdf[Iv[k] + probe] <= u1v[k]) ? step + (step >> 5) : 0;
+                        }
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+                            int I = Iv[k];
                             I -= (I * 993) >> 15;
                             I = I < last ? I : last;
                             REAL xI[NS];
 #pragma unroll
                             for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NLS + I];
                             const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn[k]));
-                            if (u2 <= thr) { Jres[k * NT + tid] = I; pend[k] = false; }
+                            if (pend[k] && u2v[k] <= thr) { Jres[k * NT + tid] = I; pend[k] = false; }
                         }
                         paris_cursor += 2ll * S;
                     }
                     // the children still pending, in index order: queue position = rank
                     if (S > 0 && !noar && paris_cursor + S > cap) paris_overflow = true;
-                    if (S > 0 && noar && (long long)(t + 1) * N * Nt > cap) paris_overflow = true;
+                    if (S > 0 && noar && paris_cursor + (long long)N * Nt > cap) paris_overflow = true;
                     if (!paris_overflow) {
 #pragma unroll
                         for (int k = 0; k < PPT; ++k) {
                             if (!pend[k]) continue;
                             const int i = k * NT + tid;
                             queue[rank[k]] = i;
-                            const double um = noar ? strm[((long long)t * N + i) * Nt + j] : strm[paris_cursor + rank[k]];
+                            const double um = noar ? strm[paris_cursor + (long long)i * Nt + j] : strm[paris_cursor + rank[k]];
                             nxt[(size_t)NS * NLS + i] = (REAL)um;
                         }
                         if (tid == 0) *qcount = S;
@@ -1130,6 +1240,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 }
                 __syncthreads();                // queue / statistic-slot scratch free for the next j
             }
+            if (ordered && (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) && !paris_overflow) paris_cursor += (long long)N * Nt;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
@@ -1271,8 +1382,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
     }
     if (PARIS && tid == 0 && P.paris_consumed) {
-        if (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) paris_cursor = (long long)N * P.Ntilde * T;
-        *P.paris_consumed = paris_overflow ? -1ll : paris_cursor;
+        P.paris_consumed[0] = paris_overflow ? -1ll : paris_cursor;
+        // RAW: a cached Gaussian is pending -> how far back from the end of the consumption its pair of doubles starts
+        P.paris_consumed[1] = (RAWCAP && raw && carry_has && !paris_overflow) ? paris_cursor - raw_slots[1] : 0ll;
     }
     if (tid == 0 && P.out) {
 #pragma unroll

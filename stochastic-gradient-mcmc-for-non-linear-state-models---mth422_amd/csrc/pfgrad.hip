@@ -631,9 +631,17 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     return fail(ctx, PFG_ERR_INVALID, id + "paris_stream_len and paris_manual_threshold must be >= 0");
                 if (q.N > pfg::MEM_MAX_N)
                     return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'paris' is implemented for N <= 16384");
+                if ((q.flags & PFG_FLAG_PARIS_RAW_STREAM) && q.N > 1024)
+                    return fail(ctx, PFG_ERR_UNSUPPORTED, id + "PFG_FLAG_PARIS_RAW_STREAM is built for N <= 1024 (one launch per timestep above)");
+                if ((q.flags & PFG_FLAG_PARIS_RAW_STREAM) && (q.z0 || q.u || q.z))
+                    return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_STREAM draws z0 / u / z from paris_stream: they must be NULL");
+                if ((q.flags & PFG_FLAG_PARIS_RAW_CARRY) && (!(q.flags & PFG_FLAG_PARIS_RAW_STREAM) || q.paris_stream_len < 1))
+                    return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_CARRY needs PFG_FLAG_PARIS_RAW_STREAM and the cached Gaussian in paris_stream[0]");
             } else if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u)))) {
                 return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools or paris_stream");
             }
+            if ((q.flags & (PFG_FLAG_PARIS_RAW_STREAM | PFG_FLAG_PARIS_RAW_CARRY)) && !q.paris_stream)
+                return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_STREAM needs paris_stream");
             if ((q.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) && !q.paris_stream)
                 return fail(ctx, PFG_ERR_UNSUPPORTED, id + "PaRIS with accept_reject = False is built for the REPLAY stream order (paris_stream)");
         } else if (q.paris_stream) {
@@ -654,8 +662,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         }
         if (!q.theta) return fail(ctx, PFG_ERR_INVALID, id + "theta is NULL");
         if (q.T > 0 && !q.y) return fail(ctx, PFG_ERR_INVALID, id + "observations are NULL");
-        if (rng == PFG_RNG_REPLAY && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
-        if (rng == PFG_RNG_REPLAY && q.T > 0 && (!q.u || !q.z)) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs u and z");
+        const bool raw_stream = q.smoother == PFG_SMOOTHER_PARIS && (q.flags & PFG_FLAG_PARIS_RAW_STREAM) != 0;
+        if (rng == PFG_RNG_REPLAY && !raw_stream && !q.init_x && !q.z0) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs z0");
+        if (rng == PFG_RNG_REPLAY && !raw_stream && q.T > 0 && (!q.u || !q.z)) return fail(ctx, PFG_ERR_INVALID, id + "REPLAY needs u and z");
         if (q.init_x && !q.init_logw) return fail(ctx, PFG_ERR_INVALID, id + "init_x needs init_logw");
         if ((q.smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC) != (ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC))
             return fail(ctx, PFG_ERR_INVALID, id + "systematic resampling cannot share a batch with other smoothers");
@@ -691,7 +700,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             size_in(q.paris_acc_u, pool);
             size_in(q.paris_man_u, (size_t)q.T * q.Ntilde * q.N);
             size_in(q.paris_stream, (size_t)q.paris_stream_len);
-            if (q.paris_stream) n_out += 1;                                   // the consumed count
+            if (q.paris_stream) n_out += 2;                                   // the consumed count, the carry-back distance
         }
         if (q.stat == PFG_STAT_PREDICTIVE && rng == PFG_RNG_REPLAY && model != PFG_MODEL_LGSSM)
             size_in(q.pred_z, (size_t)q.T * (q.num_steps_ahead + 1) * q.N);
@@ -857,7 +866,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     if (!d.paris_stream) d.paris_stream = din;        // an empty stream is still "stream order" (non-NULL)
                     d.paris_stream_len = q.paris_stream_len;
                     d.paris_manual_threshold = q.paris_manual_threshold;
-                    d.paris_consumed = reinterpret_cast<int64_t *>(take(true, 1));
+                    d.paris_consumed = reinterpret_cast<int64_t *>(take(true, 2));
                 }
             }
         }
@@ -962,7 +971,13 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
         fetch(r.rec_z0, d.rec_z0, q.N);
         fetch(r.rec_ud, d.rec_ud, (size_t)q.T * q.N);
         r.paris_consumed = 0;
-        if (d.paris_consumed) std::memcpy(&r.paris_consumed, host_of(reinterpret_cast<const double *>(d.paris_consumed)), 8);
+        r.paris_carry_back = 0;
+        if (d.paris_consumed) {
+            int64_t two[2];
+            std::memcpy(two, host_of(reinterpret_cast<const double *>(d.paris_consumed)), 16);
+            r.paris_consumed = two[0];
+            r.paris_carry_back = (int32_t)two[1];
+        }
         if (q.elementwise) {
             fetch(r.ew_mean, ew[b].mean, ew[b].Wd);
             fetch(r.ew_stats, ew[b].stats, (size_t)q.N * ew[b].Wd);

@@ -20,6 +20,8 @@ DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)
 FLAG_GARCH_STATIONARY_PRIOR = 1
 FLAG_PARIS_NO_ACCEPT_REJECT = 2
+FLAG_PARIS_RAW_STREAM = 4        # paris_stream = the window's whole np.random stream of doubles (pfgrad.h)
+FLAG_PARIS_RAW_CARRY = 8         # ... whose first entry is the generator's pending cached Gaussian
 MAX_STAT, MAX_THETA, OUT_DOUBLES, MAX_PRED, STAMP_WORDS = 4, 4, 8, 16, 16
 STATE_DIM = {"svm": 1, "garch": 2, "lgssm": 1}
 STAT_DIM = {"svm": 3, "garch": 4, "lgssm": 4}
@@ -56,7 +58,7 @@ class Result(C.Structure):
         ("mean_stat", C.c_double * MAX_STAT), ("loglik", C.c_double),
         ("x_T", _dp), ("logw_T", _dp), ("stats_T", _dp),
         ("trace_x", _dp), ("trace_logw", _dp), ("trace_stats", _dp), ("trace_ll", _dp),
-        ("status", C.c_int32), ("reserved", C.c_int32),
+        ("status", C.c_int32), ("paris_carry_back", C.c_int32),
         ("trace_anc", C.POINTER(C.c_int32)),
         ("pred", C.c_double * MAX_PRED),
         ("rec_u", C.POINTER(C.c_uint32)), ("rec_z", _dp), ("rec_z0", _dp),
@@ -84,7 +86,7 @@ RESULT_DTYPE = np.dtype([
     ("mean_stat", "f8", (MAX_STAT,)), ("loglik", "f8"),
     ("x_T", "u8"), ("logw_T", "u8"), ("stats_T", "u8"),
     ("trace_x", "u8"), ("trace_logw", "u8"), ("trace_stats", "u8"), ("trace_ll", "u8"),
-    ("status", "i4"), ("reserved", "i4"), ("trace_anc", "u8"),
+    ("status", "i4"), ("paris_carry_back", "i4"), ("trace_anc", "u8"),
     ("pred", "f8", (MAX_PRED,)),
     ("rec_u", "u8"), ("rec_z", "u8"), ("rec_z0", "u8"), ("rec_ud", "u8"), ("ew_mean", "u8"), ("ew_stats", "u8"),
     ("paris_consumed", "i8")], align=True)
@@ -346,6 +348,7 @@ class Context:
                 o["predictive"] = np.array(rs[b].pred[:int(problems[b].get("num_steps_ahead", 0)) + 1])
             if problems[b].get("paris_stream", None) is not None:
                 o["paris_consumed"] = int(rs[b].paris_consumed)
+                o["paris_carry_back"] = int(rs[b].paris_carry_back)
             for name in ("statistics", "all_statistics"):
                 if name in o:
                     o[name] = o[name][..., :h]
@@ -387,7 +390,7 @@ class Context:
                     setattr(p, name, _ptr(a))
             if arrs["weights"] is not None and arrs["weights"].shape[0] < p.tL - p.t1:
                 raise ValueError("weights shorter than tL - t1")
-            if p.rng == RNG["replay"]:
+            if p.rng == RNG["replay"] and not (p.flags & FLAG_PARIS_RAW_STREAM):
                 if arrs["u"] is None or arrs["z"] is None or arrs["u"].shape[0] != T * N or arrs["z"].shape[0] != T * N:
                     raise ValueError("replay streams u, z must have T*N entries")
                 if arrs["init_x"] is None and (arrs["z0"] is None or arrs["z0"].shape[0] != N):

@@ -267,7 +267,10 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
                      t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=1.0, Ntilde=paris_kw["Ntilde"],
                      prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
                      prior_var=float(np.asarray(prior_var).reshape(-1)[0]), y=y, weights=weights, theta=theta, flags=flags)
-            q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state)
+            if int(N) <= 1024:
+                q["_result"] = _paris_raw_window(q, accept_reject, mar, mst, random_state)      # the whole window in one launch
+            else:
+                q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state)   # one launch per timestep
             return q
         # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
         # left and draws those exactly (its own cap is 100 log10(N/10) rounds); a fixed number of
@@ -318,6 +321,75 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
 
 
 _paris_block_hint = {}          # (N, Ntilde) -> doubles a timestep's backward sampling consumed last time (stream block size)
+_paris_raw_hint = {}            # (N, Ntilde, accept_reject) -> doubles per timestep a whole window consumed last time
+_RAW_CHUNK = 1 << 16            # the raw stream is drawn in chunks with the generator state kept at every boundary
+
+
+def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None):
+    """One PaRIS window (N <= 1024) consuming the legacy generator EXACTLY as the reference does, in ONE launch
+    (pfgrad.h: PFG_FLAG_PARIS_RAW_STREAM): the host hands the kernel what RandomState.random_sample delivers from the
+    generator's current state, the kernel takes from it -- in np.random's order -- the normals of x0 and per timestep N
+    uniforms, N normals (NumPy's legacy polar method on pairs of doubles, the second variate of a pair cached) and the
+    backward sampling's uniforms, and reports how many doubles it consumed.  The generator is then put where the
+    reference's stands: advanced by that many doubles, its cached Gaussian (if one is pending) recomputed here from the
+    pair of doubles the kernel points at, with the host libm NumPy uses.  Returns what _paris_replay_window returns
+    minus the all_* traces (buffered_pf_wrapper(save_all=True) re-runs the launch on the same doubles for those)."""
+    import math
+    ctx = _capi.default_context()
+    rs = np.random if random_state is None else random_state
+    N, Nt, y = q["N"], q["Ntilde"], q["y"]
+    T = y.shape[0]
+    h = _capi.STAT_DIM[q["model"]] if q["stat"] == "score" else 3
+    mar = int(100 * np.log10(N / 10)) if max_accept_reject is None else int(max_accept_reject)
+    mst = int(10 * np.log10(N / 10)) if manual_sample_threshold is None else int(manual_sample_threshold)
+    mar, mst = max(mar, 0), max(mst, 0)
+    state0 = rs.get_state()
+    has_gauss, cached = int(state0[3]), float(state0[4])
+    flags = int(q.get("flags", 0)) | _capi.FLAG_PARIS_RAW_STREAM
+    flags |= 0 if accept_reject else _capi.FLAG_PARIS_NO_ACCEPT_REJECT
+    flags |= _capi.FLAG_PARIS_RAW_CARRY if has_gauss else 0
+    key = (N, Nt, bool(accept_reject))
+    normals = int(1.36 * N) + 64                     # doubles of one call: N / 2 pairs accepted with probability pi / 4
+    per_step = _paris_raw_hint.get(key, 0) * 1.2 or (N + normals + (N * Nt if not accept_reject else 8 * N * Nt))
+    L = int(normals + T * per_step) + 4 * 1024 + 4096     # + the kernel's look-ahead of one round of attempts
+    while True:
+        L = (L + _RAW_CHUNK - 1) // _RAW_CHUNK * _RAW_CHUNK
+        stream = np.empty(L + 1)
+        stream[0] = cached
+        states = []
+        for c0 in range(0, L, _RAW_CHUNK):
+            states.append(rs.get_state())
+            stream[1 + c0:1 + c0 + _RAW_CHUNK] = rs.random_sample(_RAW_CHUNK)
+        s0 = 0 if has_gauss else 1                  # without a cached Gaussian the doubles start at stream[1]
+        run = dict(model=q["model"], kernel=q["kernel"], smoother="paris", stat=q["stat"], dtype="f64", rng="replay", N=N,
+                   t1=q["t1"], tL=q["tL"], lambduh=1.0, theta=q["theta"], prior_mean=q["prior_mean"], prior_var=q["prior_var"],
+                   y=y, weights=q.get("weights", None), Ntilde=Nt, max_accept_reject=mar, paris_manual_threshold=mst,
+                   paris_stream=stream[s0:], flags=flags)
+        o = ctx.run_batch([run], want_final=True)[0]
+        used = o["paris_consumed"]
+        if used >= 0:
+            break
+        rs.set_state(state0)
+        L *= 2                                      # the stream ran out: the same window again on a longer one
+    drawn = used - (1 if has_gauss else 0)          # doubles taken from the generator
+    _paris_raw_hint[key] = drawn / max(T, 1)
+    c = min(drawn // _RAW_CHUNK, len(states) - 1)
+    rs.set_state(states[c])
+    if drawn - c * _RAW_CHUNK > 0:
+        rs.random_sample(drawn - c * _RAW_CHUNK)    # the generator now stands where the reference's stands ...
+    st = rs.get_state()
+    back = o["paris_carry_back"]
+    if back > 0:                                    # ... including legacy_gauss' cached second variate
+        d0, d1 = stream[s0 + used - back], stream[s0 + used - back + 1]
+        x1, x2 = 2.0 * d0 - 1.0, 2.0 * d1 - 1.0
+        r2 = x1 * x1 + x2 * x2
+        rs.set_state((st[0], st[1], st[2], 1, math.sqrt(-2.0 * math.log(r2) / r2) * x1))
+    else:
+        rs.set_state((st[0], st[1], st[2], 0, 0.0))
+    stats = o["statistics"][:, :h]
+    return dict(mean_stat=np.asarray(o["mean_stat"])[:h], loglik=o["loglik"], x_t=o["x_t"], log_weights=o["log_weights"],
+                statistics=stats, _draws=dict(paris_stream=stream[s0:s0 + used + 4096].copy(), flags=flags, max_accept_reject=mar,
+                                              paris_manual_threshold=mst, _consumed=used))     # (+ the kernel's look-ahead)
 
 
 def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None):
@@ -406,6 +478,9 @@ def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
     q = make_problem(model, kernel, pf, observations, theta, N, **kwargs)
     ctx = ctx or _capi.default_context()
     if "_result" in q:                  # PaRIS in np.random's order: the window ran while its draws were due
+        if save_all and "all_x_t" not in q["_result"]:      # (one launch, no traces kept: the same launch again with them)
+            o = ctx.run_batch([paris_replay_again(q)], want_final=True, want_trace=True)[0]
+            return _to_reference_dict(o, q)
         return _to_reference_dict(q["_result"], q)
     o = ctx.run_batch([q], want_final=want_final or save_all, want_trace=save_all)[0]
     out = _to_reference_dict(o, q)

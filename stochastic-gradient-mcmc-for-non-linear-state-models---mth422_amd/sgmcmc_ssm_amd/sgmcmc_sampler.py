@@ -195,8 +195,9 @@ class PFHelper(object):
             # window once more in one launch, on the same numbers, with the elementwise pass behind it
             q2 = _pf.paris_replay_again(q)
             o = _capi.default_context().run_batch([q2], want_elementwise=True)[0]
-            if o["paris_consumed"] != q2["paris_stream"].shape[0]:
-                raise RuntimeError("PaRIS replay consumed {0} of {1} uniforms".format(o["paris_consumed"], q2["paris_stream"].shape[0]))
+            expected = q2.get("_consumed", q2["paris_stream"].shape[0])
+            if o["paris_consumed"] != expected:
+                raise RuntimeError("PaRIS replay consumed {0} of {1} uniforms".format(o["paris_consumed"], expected))
         else:
             o = _capi.default_context().run_batch([q], want_elementwise=True)[0]
         _pf._recycle_streams([q])

@@ -297,3 +297,79 @@ def test_paris_stream_too_short_is_reported_and_retried(ctx):
     from test_host_logic import vec
     np.testing.assert_allclose(vec("svm", grad), g.get(key, "grad"), rtol=1e-9)
     assert np.random.random_sample() == float(g.get(key, "next_draw"))
+
+
+@pytest.mark.parametrize("model,kernel,N,T,pre", [("svm", "prior", 1000, 40, 0), ("svm", "prior", 257, 30, 1), ("garch", "optimal", 300, 25, 1),
+                                                 ("lgssm", "optimal", 64, 50, 0), ("lgssm", "prior", 999, 12, 3), ("svm", "prior", 1, 9, 1)])
+@pytest.mark.parametrize("accept_reject", [True, False])
+def test_paris_whole_window_in_one_launch(ctx, monkeypatch, model, kernel, N, T, pre, accept_reject):
+    """PFG_FLAG_PARIS_RAW_STREAM (N <= 1024): the kernel takes everything from one stream of doubles in np.random's order,
+    NumPy's legacy Gaussians included (polar method, cached second variate -- `pre` odd leaves one pending on entry, odd N
+    leaves one pending on exit).  Against the CPU oracle consuming the same RandomState (bit-exact to the reference,
+    tests/test_oracle_golden.py) at rtol 1e-9, the generator afterwards bit for bit where the oracle's is (key, position,
+    cached Gaussian), and against the one-launch-per-timestep path on the same seed."""
+    from sgmcmc_ssm_amd import particle_filters as pfm
+    from test_host_logic import default_params, GEN
+    np.random.seed(4)
+    p = default_params(model)
+    y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
+    w = np.random.uniform(0.5, 2.0, size=T - 5)
+    kw = dict(t1=2, tL=T - 3, weights=w, prior_mean=0.1, prior_var=1.3)
+    ref_rs, rs = np.random.RandomState(99), np.random.RandomState(99)
+    for _ in range(pre):
+        ref_rs.normal(); rs.normal(); ref_rs.random_sample(2); rs.random_sample(2)
+    ref = po.pf_window_paris_rng(model, p.theta(), y, N, rng=ref_rs, kernel=kernel, stat="score", Ntilde=2,
+                                 accept_reject=accept_reject, **kw)
+    calls = []
+    real = pfm._paris_raw_window
+    monkeypatch.setattr(pfm, "_paris_raw_window", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    out = pfm.buffered_pf_wrapper("paris", model, kernel, y, p.theta(), N, random_state=rs, accept_reject=accept_reject, **kw)
+    assert calls == [1]
+    np.testing.assert_allclose(out["mean_statistic"], ref["mean_statistic"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["loglikelihood_estimate"], ref["loglikelihood_estimate"], rtol=1e-9)
+    np.testing.assert_allclose(out["x_t"][:, 0], ref["x_t"][:, 0], rtol=1e-9, atol=1e-9)
+    a, b = rs.get_state(), ref_rs.get_state()
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    assert rs.normal() == ref_rs.normal() and rs.random_sample() == ref_rs.random_sample()
+    # the per-timestep path (host-drawn u / z, libm normals) on the same seed: same numbers to rounding, same generator
+    rs2 = np.random.RandomState(99)
+    for _ in range(pre):
+        rs2.normal(); rs2.random_sample(2)
+    monkeypatch.setattr(pfm, "_paris_raw_window", pfm._paris_replay_window)
+    step = pfm.buffered_pf_wrapper("paris", model, kernel, y, p.theta(), N, random_state=rs2, accept_reject=accept_reject, **kw)
+    np.testing.assert_allclose(out["mean_statistic"], step["mean_statistic"], rtol=1e-10, atol=1e-10)
+    c = rs2.get_state()
+    assert np.array_equal(a[1], c[1]) and a[2:] == c[2:]
+
+
+def test_paris_one_launch_stream_too_short_and_refusals(ctx, monkeypatch):
+    """A raw stream that runs out is reported (-1) and the host draws a longer one; the flag's preconditions are checked."""
+    from sgmcmc_ssm_amd import _capi, particle_filters as pfm
+    from test_host_logic import default_params, GEN
+    np.random.seed(4)
+    p = default_params("svm")
+    T, N = 30, 500
+    y = GEN["svm"](T=T, parameters=p)["observations"].reshape(-1)
+    ref_rs = np.random.RandomState(7)
+    ref = po.pf_window_paris_rng("svm", p.theta(), y, N, rng=ref_rs, kernel="prior", stat="score", Ntilde=2, t1=0, tL=T,
+                                 prior_mean=0.0, prior_var=1.0)
+    monkeypatch.setitem(pfm._paris_raw_hint, (N, 2, True), 10.0)           # a hopeless first guess: two retries
+    runs = []
+    real = _capi.Context.run_batch
+    monkeypatch.setattr(_capi.Context, "run_batch", lambda self, *a, **k: (runs.append(1), real(self, *a, **k))[1])
+    rs = np.random.RandomState(7)
+    out = pfm.buffered_pf_wrapper("paris", "svm", "prior", y, p.theta(), N, random_state=rs, prior_mean=0.0, prior_var=1.0)
+    assert len(runs) >= 2
+    np.testing.assert_allclose(out["mean_statistic"], ref["mean_statistic"], rtol=1e-9, atol=1e-9)
+    assert rs.random_sample() == ref_rs.random_sample()
+    monkeypatch.undo()
+    base = dict(model="svm", kernel="prior", smoother="paris", stat="score", dtype="f64", rng="replay", N=N, t1=0, tL=T, lambduh=1.0,
+                theta=p.theta(), prior_mean=0.0, prior_var=1.0, y=y, Ntilde=2, max_accept_reject=30, paris_manual_threshold=5,
+                paris_stream=np.random.random_sample(200), flags=_capi.FLAG_PARIS_RAW_STREAM)
+    assert ctx.run_batch([dict(base)], want_final=True)[0]["paris_consumed"] == -1
+    with pytest.raises(ValueError, match="must be NULL"):
+        ctx.run_batch([dict(base, z0=np.zeros(N), u=np.zeros((T, N)), z=np.zeros((T, N)))])
+    with pytest.raises(NotImplementedError, match="N <= 1024"):
+        ctx.run_batch([dict(base, N=2000)])
+    with pytest.raises(ValueError, match="RAW_CARRY|replay streams"):          # the binding refuses it before the library does
+        ctx.run_batch([dict(base, flags=_capi.FLAG_PARIS_RAW_CARRY)])
