@@ -83,6 +83,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     const pfg_dev_problem &P = probs[blockIdx.x];
     const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    if (PARIS && (P.flags & PFG_FLAG_PARIS_RAW_STREAM)) {
+        // the whole-window stream is understood by the LDS-resident PaRIS kernel only (N <= 1024): a descriptor that asks
+        // for it here has no u / z to fall back on -- report "stream too short" instead of reading NULL
+        if (tid == 0 && P.paris_consumed) P.paris_consumed[0] = -1ll;
+        return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int nchunk = (N + NT - 1) / NT;
     const int np2 = mem_np2(N);
