@@ -637,6 +637,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_STREAM draws z0 / u / z from paris_stream: they must be NULL");
                 if ((q.flags & PFG_FLAG_PARIS_RAW_CARRY) && (!(q.flags & PFG_FLAG_PARIS_RAW_STREAM) || q.paris_stream_len < 1))
                     return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_CARRY needs PFG_FLAG_PARIS_RAW_STREAM and the cached Gaussian in paris_stream[0]");
+                if ((q.flags & PFG_FLAG_PARIS_RAW_CARRY) && q.init_x && q.T == 0)
+                    return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_CARRY with a warm start and T = 0 draws no normal: nothing to carry the cached Gaussian through");
             } else if (rng == PFG_RNG_REPLAY && (!q.paris_man_u || (q.max_accept_reject > 0 && (!q.paris_idx_u || !q.paris_acc_u)))) {
                 return fail(ctx, PFG_ERR_INVALID, id + "REPLAY paris needs the paris_* uniform pools or paris_stream");
             }
