@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 121          /* 0.1.21 */
+#define PFG_VERSION 122          /* 0.1.22 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -269,6 +269,20 @@ int pfg_last_traced(pfg_ctx *ctx);
  * the plain entry point serves NEMETH / FILTER) */
 int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother,
                                int n_max, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
+/* N above the one-workgroup kernels' maximum (16384 < N <= 4194304; the reference has no limit and its bias experiments
+ * call pf_gradient_estimate with N = 1000000: gradient_error_fig_scripts/svm_grad_compare.py:68-82): every window of the
+ * batch runs as a WHOLE-GPU window -- the particle axis cut into tiles of 1024 / 2048 particles, one workgroup each, one
+ * kernel launch per timestep (T_max + 2 launches on `hip_stream`; REPLAY: 2 T_max + 2, the extra one per timestep builds
+ * the reference's CDF -- NumPy's sequential cumsum, bit for bit -- in one workgroup per window).  T_max = the largest T of
+ * the batch (the host issues the launches, so it has to know; shorter windows leave theirs at once).  NEMETH / FILTER
+ * with the score, sufficient or no statistic.  Every descriptor needs `scratch` of pfg_scratch_bytes(model, dtype, rng, N)
+ * bytes (256-byte aligned); windows of one batch must all have N <= 262144 or all N > 262144 (the tile size differs).
+ * DEVICE rng: the resampling uniforms are SORTED uniforms (exponential spacings, rec_ud), generator lane = particle
+ * index mod tile; out[7] = 1.  REPLAY: u / z as for every kernel, out[7] = the smallest |u - cdf| margin of the run.
+ * pfg_run / pfg_run_batch route N > 16384 here by themselves (PFGRAD_VARIANT=grid forces it for smaller N). */
+int pfg_launch_device_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int T_max, int B,
+                           const pfg_dev_problem *dev_probs, void *hip_stream);
+
 /* Buffered-subsequence sampling for resident chains, on the device: for every descriptor b draw
  * a window start as SGMCMCSampler._random_subsequence_and_buffers does (sgmcmc_sampler.py:259-288;
  * 'uniform' style: start ~ U{0..T-S}; strict != 0: start = S * U{0..T/S-1}), keyed by
@@ -282,8 +296,8 @@ int pfg_sample_windows_device(pfg_ctx *ctx, int B, pfg_dev_problem *dev_probs, c
                               void *hip_stream);
 
 /* bytes of per-problem HBM scratch (pfg_dev_problem.scratch, 256-byte aligned) the large-N
- * kernel needs for (model, dtype, rng, N); 0 when an LDS-resident variant serves this size,
- * -1 when N is above the supported maximum (16384) */
+ * kernel (N <= 16384) or the whole-GPU window (N <= 4194304) needs for (model, dtype, rng, N); 0 when an LDS-resident
+ * variant serves this size, -1 when N is above the supported maximum */
 int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N);
 /* name of the kernel variant pfg_launch_device would pick (for profiles / logs) */
 const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_max);

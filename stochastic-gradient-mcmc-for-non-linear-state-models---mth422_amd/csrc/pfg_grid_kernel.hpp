@@ -1,0 +1,695 @@
+// libpfgrad device code: the WHOLE-GPU window for giant particle counts (MEM_MAX_N < N <= GRID_MAX_N).
+//
+// Every other kernel of the library runs one window in one workgroup (the T-loop never leaves a CU).  The reference's
+// bias experiments call the hot-path entry with N = 10^6 particles on 48-step windows
+// (nonlinear_ssm_pf_experiment_scripts/gradient_error_fig_scripts/svm_grad_compare.py:68-82, garch_grad_compare.py:86;
+// particle_filters/pf.py:7-38 has no N limit): there ONE window is 80 MB of state per timestep, the byte roofline of
+// SURVEY 8(d) is the real bound, and the particle axis of the window is what has to be spread over the 256 CUs.
+//
+// Structure: the particle axis is cut into tiles of TILE = NT * GRID_PPT particles, one workgroup per tile; one kernel
+// launch per timestep (a dependent launch boundary is ~1.5 us, a software grid barrier 4-7 us, and a boundary also
+// makes the other XCDs' L2 see this step's children).  State lives in a per-window HBM scratch:
+//     lw[2][N]            log-weights, ping-pong by timestep parity
+//     rec[2][N][REC]      particle records {x[NS], stats[H], pad} (array of records: a parent gather is 2-3 16-byte
+//                         vectors from one place), ping-pong
+//     partials[2][..]     per tile: maximum log-weight m_b, W_b = sum exp(lw - m_b), S_b[h] = sum stats_h exp(lw - m_b),
+//                         E_b = total of the tile's exponential spacings (device generator); written by the launch that
+//                         CREATES the particles (its epilogue), reduced redundantly by every workgroup of the next launch
+//                         (G <= 2048 values): the step needs no separate reduction pass and no grid-wide synchronisation
+//     rng[G*NT]           jsf32 lane-generator states between launches (device generator)
+//     head[32]            log-likelihood, filter accumulators, tie margin
+//     REPLAY only: cdf[N] (the reference's CDF, bit for bit: pfg_grid_cdf.hpp), coarse[C], walk list
+//
+// DEVICE generator (the throughput path, pfg_grid_step_kernel<.., PFG_RNG_DEVICE>): the resampling uniforms of a timestep
+// are the order statistics of N i.i.d. uniforms (exponential spacings, as pf_big_kernel; multinomial resampling does not
+// care which child gets which uniform), child r takes U_(r).  Children AND parents are then both sorted along the particle
+// axis: the children of tile b descend from a contiguous run of parents, which the workgroup finds with a search over the
+// tiles' cumulative weights and walks tile by tile -- per parent tile it rebuilds the tile's CDF segment in LDS from the
+// log-weights (8 B per parent; no CDF array in memory), searches it, gathers the parent records (monotone addresses:
+// coalesced) and writes its children.  Traffic per particle-step: lw read (>= 8 B) + record read + record write + lw write
+// = 2 (n + 1 + h) w bytes, the algorithmic figure of SURVEY 8(d).
+//
+// REPLAY (the reference's own np.random stream: child i takes u[t][i], z[t][i]): the CDF has to be the reference's --
+// cumsum(p) / cumsum(p)[-1] with the roundings of a SEQUENTIAL fp64 sum, see pfg_grid_cdf.hpp for why and how -- it is
+// materialised in HBM by pfg_grid_cdf_kernel (one workgroup per window), and the step kernel searches it with i.i.d.
+// uniforms: a coarse table (every S-th entry, <= 16384 doubles) in LDS, then log2(S) probes in memory.
+#pragma once
+#include "pfg_big_kernel.hpp"
+
+namespace pfg {
+
+constexpr int GRID_MAX_N = 1 << 22;
+constexpr int GRID_PPT = 4;
+constexpr int GRID_MAX_TILES = 2048;
+constexpr int GRID_COARSE_MAX = 16384;
+constexpr int GRID_HEAD_DOUBLES = 32;
+// head slots
+constexpr int GH_LL = 0, GH_FILT = 1 /* ..4 */, GH_TIE = 5, GH_WALK = 6, GH_M = 7, GH_W = 8, GH_S = 9 /* ..12 */, GH_ERR = 13;
+
+__host__ __device__ inline int grid_nt(int N) { return N <= (1 << 18) ? 256 : 512; }
+
+struct GridLayout {
+    int N, NT, TILE, G, C, S, PSTRIDE;          // C coarse entries of stride S (REPLAY); PSTRIDE doubles per partial parity
+    size_t lw[2], rec[2], part[2], rng, head, cdf, coarse, walk_i, walk_p, walk_q, walk_s, bytes;
+};
+
+// partials of one parity: pm[G] | pW[G] | pE[G] | pS[4][G] | extra[8]  (extra[0] = the (N+1)-th spacing)
+__host__ __device__ inline size_t grid_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int MODEL, typename REAL>
+__host__ __device__ inline GridLayout grid_layout(int N, bool replay) {
+    GridLayout L;
+    L.N = N;
+    L.NT = grid_nt(N);
+    L.TILE = L.NT * GRID_PPT;
+    L.G = (N + L.TILE - 1) / L.TILE;
+    int S = 64;
+    while ((N + S - 1) / S > GRID_COARSE_MAX) S <<= 1;
+    L.S = S;
+    L.C = (N + S - 1) / S;
+    L.PSTRIDE = 7 * L.G + 8;
+    constexpr int REC = mem_rec_len<MODEL, REAL>();
+    size_t o = 0;
+    for (int q = 0; q < 2; ++q) { L.lw[q] = o; o = grid_align(o + (size_t)N * sizeof(REAL)); }
+    for (int q = 0; q < 2; ++q) { L.rec[q] = o; o = grid_align(o + (size_t)N * REC * sizeof(REAL)); }
+    for (int q = 0; q < 2; ++q) { L.part[q] = o; o = grid_align(o + (size_t)L.PSTRIDE * 8); }
+    L.rng = o; o = grid_align(o + (size_t)L.G * L.NT * 16);
+    L.head = o; o = grid_align(o + GRID_HEAD_DOUBLES * 8);
+    L.cdf = L.coarse = L.walk_i = L.walk_p = L.walk_q = L.walk_s = o;
+    if (replay) {
+        L.cdf = o; o = grid_align(o + (size_t)N * 8);
+        L.coarse = o; o = grid_align(o + (size_t)L.C * 8);
+        L.walk_i = o; o = grid_align(o + (size_t)N * 4);
+        L.walk_p = o; o = grid_align(o + (size_t)N * 8);
+        L.walk_q = o; o = grid_align(o + (size_t)N * 8);
+        L.walk_s = o; o = grid_align(o + (size_t)N * 8);
+    }
+    L.bytes = o;
+    return L;
+}
+
+// ---- small workgroup-level helpers (NT threads, NW = NT / 64 waves) -------------------------------------------------
+template <int NW>
+__device__ __forceinline__ double block_max_f64(double v, double *red, int wave, int lane) {
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = red[w] > m ? red[w] : m;
+    return uniform_f64(m);
+}
+template <int NW>
+__device__ __forceinline__ double block_sum_f64(double v, double *red, int wave, int lane) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];          // fixed order: every workgroup gets the same bits
+    return uniform_f64(s);
+}
+
+// Inclusive scan of PPT values per thread over the tile in RANK order r = k * NT + tid (k-major), fixed summation order:
+// the owner's epilogue (tile total W_b) and every rebuild of the tile by another workgroup produce the same bits.
+// red: [PPT * NW + PPT * NW] doubles.  Returns the tile total.
+template <int NT, int PPT>
+__device__ __forceinline__ double tile_scan(const double (&p)[PPT], double (&c)[PPT], double *red, int wave, int lane) {
+    constexpr int NW = NT / WAVE;
+    double inc[PPT];
+    __syncthreads();                                        // red may still be read from an earlier use
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        inc[k] = wave_incl_scan(p[k]);
+        if (lane == WAVE - 1) red[k * NW + wave] = inc[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // exclusive offsets of the PPT * NW (<= 64) wave totals in (k, wave) order: one per lane
+        const int idx = lane;
+        const double v = idx < PPT * NW ? red[idx] : 0.0;
+        const double in = wave_incl_scan(v);
+        const double up = __shfl_up(in, 1);
+        if (idx < PPT * NW) red[PPT * NW + idx] = lane == 0 ? 0.0 : up;
+        if (lane == WAVE - 1) red[2 * PPT * NW] = in;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) c[k] = inc[k] + red[PPT * NW + k * NW + wave];
+    return uniform_f64(red[2 * PPT * NW]);
+}
+
+// What every workgroup of a launch derives from the G tile partials of the particles it is about to resample.
+struct GridReduced {
+    double m, W, invW;
+    double S[PFG_MAX_STAT];
+    double PE_own, invEtot;          // device generator: spacings before this tile, 1 / total of the N + 1 spacings
+};
+
+// pw_lds: [G + 1] exclusive prefix of W_b * exp(m_b - m) over the tiles (pw_lds[G] = W).  Fixed order.
+template <int NT, typename MATH>
+__device__ __forceinline__ GridReduced grid_reduce_partials(const double *__restrict__ part, int G, int b_own, bool needS, bool needE,
+                                                            int H, const MATH &mth, double *pw_lds, double *red, int tid) {
+    constexpr int NW = NT / WAVE;
+    const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const double *pm = part, *pW = part + G, *pE = part + 2 * (size_t)G, *pS = part + 3 * (size_t)G;
+    GridReduced R;
+    double ml = -INFINITY;
+    for (int b = tid; b < G; b += NT) { const double v = pm[b]; ml = v > ml ? v : ml; }
+    R.m = block_max_f64<NW>(ml, red, wave, lane);
+    // thread `tid` owns the K consecutive tiles [tid K, tid K + K): local running sums, one wave scan, wave offsets
+    const int K = (G + NT - 1) / NT;                        // <= 8
+    double v[8], loc = 0.0, sl[PFG_MAX_STAT] = {0.0, 0.0, 0.0, 0.0}, el = 0.0, eown = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[q] = 0.0;
+        const int b = tid * K + q;
+        if (q < K && b < G) {
+            const double sc = ::exp(pm[b] - R.m);
+            v[q] = pW[b] * sc;
+            loc += v[q];
+            if (needS) {
+                for (int h = 0; h < H; ++h) sl[h] += pS[(size_t)h * G + b] * sc;
+            }
+            if (needE) { const double e = pE[b]; el += e; eown += b < b_own ? e : 0.0; }
+        }
+    }
+    (void)mth;
+    const double inc = wave_incl_scan(loc);
+    __syncthreads();
+    if (lane == WAVE - 1) red[wave] = inc;
+    __syncthreads();
+    double woff = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const double x = red[w]; woff += w < wave ? x : 0.0; tot += x; }
+    double run = woff + (inc - loc);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int b = tid * K + q;
+        if (q < K && b < G) pw_lds[b] = run;
+        run += v[q];
+    }
+    if (tid == 0) pw_lds[G] = tot;
+    R.W = uniform_f64(tot);
+    R.invW = uniform_f64(1.0 / R.W);
+#pragma unroll
+    for (int h = 0; h < PFG_MAX_STAT; ++h) R.S[h] = 0.0;
+    if (needS) {
+        for (int h = 0; h < H; ++h) R.S[h] = block_sum_f64<NW>(sl[h], red, wave, lane) * R.invW;
+    }
+    R.PE_own = 0.0; R.invEtot = 0.0;
+    if (needE) {
+        const double et = block_sum_f64<NW>(el, red, wave, lane);
+        R.PE_own = block_sum_f64<NW>(eown, red, wave, lane);
+        R.invEtot = uniform_f64(1.0 / (et + part[7 * (size_t)G]));
+    }
+    __syncthreads();                                        // pw_lds complete
+    return R;
+}
+
+// atomic minimum of a non-negative double (its bit pattern orders like an unsigned integer)
+__device__ __forceinline__ void atomic_min_pos_f64(double *addr, double v) {
+    atomicMin(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+template <int MODEL, typename REAL, int RNG>
+using GridMath = Math<REAL, (RNG == PFG_RNG_DEVICE)>;
+
+template <int NT, typename REAL, int RNG>
+__host__ __device__ constexpr size_t grid_step_lds_bytes(int C) {
+    // pw [G+1 <= 2049] | tile CDF [TILE] or coarse [C] | red [4 PPT NW + 16] | tables
+    return (size_t)(GRID_MAX_TILES + 1) * 8 +
+           (RNG == PFG_RNG_DEVICE ? (size_t)NT * GRID_PPT * 8 + (size_t)GRID_MAX_TILES / 8 : (size_t)C * 8) +
+           (size_t)(4 * GRID_PPT * (NT / WAVE) + 16 + PFG_MAX_STAT * (NT / WAVE)) * 8 + tab_bytes<REAL, RNG, (RNG == PFG_RNG_DEVICE)>();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue shared by the init and step kernels: the partials of the particles this workgroup has just created (their
+// log-weights in lwn[], statistics in sn[][]), for the launch that will resample them.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int H, typename REAL, typename MATH>
+__device__ __forceinline__ void grid_tile_partials(double *__restrict__ part, int G, int b, int N, const REAL (&lwn)[GRID_PPT],
+                                                   const REAL (&sn)[GRID_PPT][H], bool needS, const MATH &mth, double *red, int tid) {
+    constexpr int NW = NT / WAVE, PPT = GRID_PPT;
+    const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    double ml = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const bool v = b * (NT * PPT) + k * NT + tid < N;
+        const double l = v ? (double)lwn[k] : -INFINITY;
+        ml = l > ml ? l : ml;
+    }
+    const double mb = block_max_f64<NW>(ml, red, wave, lane);
+    double p[PPT], c[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const bool v = b * (NT * PPT) + k * NT + tid < N;
+        p[k] = v ? (double)mth.exp_acc((REAL)((double)lwn[k] - mb)) : 0.0;
+    }
+    const double Wb = tile_scan<NT, PPT>(p, c, red, wave, lane);
+    if (tid == 0) { part[b] = mb; part[G + b] = Wb; }
+    if (needS) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) a += (double)sn[k][h] * p[k];
+            const double s = block_sum_f64<NW>(a, red, wave, lane);
+            if (tid == 0) part[(size_t)(3 + h) * G + b] = s;
+        }
+    }
+}
+
+// spacings of the NEXT resampling step for this tile's children (device generator): the tile total, from a COPY of the
+// lane generator -- the step kernel regenerates the same words from the saved state
+template <int NT>
+__device__ __forceinline__ void grid_tile_spacings(double *__restrict__ part, int G, int b, int N, LaneRng rng, double *red, int tid) {
+    constexpr int NW = NT / WAVE, PPT = GRID_PPT;
+    const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    double e[PPT], c[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const float ef = spacing_f32(rng.next());
+        e[k] = (b * (NT * PPT) + k * NT + tid < N) ? (double)ef : 0.0;
+    }
+    const float extra = spacing_f32(rng.next());
+    const double Eb = tile_scan<NT, PPT>(e, c, red, wave, lane);
+    if (tid == 0) {
+        part[2 * (size_t)G + b] = Eb;
+        if (b == 0) part[7 * (size_t)G] = (double)extra;    // spacing N + 1: part of the total only
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// init: x0 (or warm start), zero statistics and log-weights, partials of step 0, generator states
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODEL, int KERNEL, typename REAL, int RNG, int NT>
+__global__ __launch_bounds__(NT) void pfg_grid_init_kernel(const pfg_dev_problem *__restrict__ probs) {
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT;
+    constexpr int REC = mem_rec_len<MODEL, REAL>();
+    extern __shared__ __align__(16) unsigned char smem[];
+    const pfg_dev_problem &P = probs[blockIdx.y];
+    const int N = P.N, b = blockIdx.x, tid = threadIdx.x;
+    const GridLayout L = grid_layout<MODEL, REAL>(N, RNG == PFG_RNG_REPLAY);
+    if (b >= L.G) return;
+    char *base = static_cast<char *>(P.scratch);
+    gptr<REAL> lw = global_ptr(reinterpret_cast<REAL *>(base + L.lw[0]));
+    gptr<REAL> rec = global_ptr(reinterpret_cast<REAL *>(base + L.rec[0]));
+    double *part = reinterpret_cast<double *>(base + L.part[0]);
+    double *head = reinterpret_cast<double *>(base + L.head);
+    double *red = reinterpret_cast<double *>(smem);
+    double *tabmem = red + (4 * PPT * (NT / WAVE) + 16 + PFG_MAX_STAT * (NT / WAVE));
+    GridMath<MODEL, REAL, RNG> mth;
+    mth.t.e2 = tabmem;
+    mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
+    mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
+    if (tab_bytes<REAL, RNG, (RNG == PFG_RNG_DEVICE)>() > 0) tab_fill(tabmem, true, tid, NT);
+    const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
+    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
+    if (b == 0 && tid < GRID_HEAD_DOUBLES) head[tid] = tid == GH_TIE ? 1.0 : 0.0;
+    LaneRng rng = {};
+    if (RNG == PFG_RNG_DEVICE) rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)(b * NT + tid));
+    double pv = P.prior_var;
+    if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
+        pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
+    const double sd = sqrt(pv);
+    REAL lwn[PPT], sn[PPT][H];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = b * TILE + k * NT + tid;
+        REAL x[NS], l0 = (REAL)0;
+#pragma unroll
+        for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) sn[k][h] = (REAL)0;
+        REAL za = (REAL)0, zb = (REAL)0;
+        if (RNG == PFG_RNG_DEVICE && !P.init_x) mth.normal_pair(rng.next(), rng.next(), za, zb);
+        lwn[k] = l0;
+        if (i < N) {
+            if (P.init_x) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) x[d] = (REAL)P.init_x[(size_t)i * NS + d];
+                l0 = (REAL)P.init_logw[i];
+                if (P.init_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) sn[k][h] = (REAL)P.init_stats[(size_t)i * H + h];
+                }
+            } else {
+                const double z = RNG == PFG_RNG_REPLAY ? P.z0[i] : (double)za;
+                x[0] = (REAL)(P.prior_mean + sd * z);
+                if (RNG == PFG_RNG_DEVICE && P.rec_z0) P.rec_z0[i] = z;
+            }
+            lwn[k] = l0;
+            lw[i] = l0;
+            alignas(16) REAL r[REC] = {};
+#pragma unroll
+            for (int d = 0; d < NS; ++d) r[d] = x[d];
+#pragma unroll
+            for (int h = 0; h < H; ++h) r[NS + h] = sn[k][h];
+            rec_store<REC, REAL>(rec + (size_t)i * REC, r);
+            if (P.trace_x) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
+                P.trace_logw[i] = (double)l0;
+                if (P.trace_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) P.trace_stats[(size_t)i * H + h] = (double)sn[k][h];
+                }
+            }
+        }
+    }
+    const bool needS = is_filter || P.lambduh != 1.0 || P.T == 0;
+    grid_tile_partials<NT, H, REAL>(part, L.G, b, N, lwn, sn, needS, mth, red, tid);
+    if (RNG == PFG_RNG_DEVICE) {
+        if (P.T > 0) grid_tile_spacings<NT>(part, L.G, b, N, rng, red, tid);
+        reinterpret_cast<uint4 *>(base + L.rng)[b * NT + tid] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one timestep t (0 <= t < T): resample the particles of parity t & 1, propose, weight, accumulate, write parity (t+1) & 1
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODEL, int KERNEL, typename REAL, int RNG, int NT>
+__global__ __launch_bounds__(NT) void pfg_grid_step_kernel(const pfg_dev_problem *__restrict__ probs, int t) {
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT, NW = NT / WAVE;
+    constexpr int REC = mem_rec_len<MODEL, REAL>();
+    constexpr bool DEV = RNG == PFG_RNG_DEVICE;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const pfg_dev_problem &P = probs[blockIdx.y];
+    const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL, b = blockIdx.x, tid = threadIdx.x;
+    if (t >= T) return;
+    const GridLayout L = grid_layout<MODEL, REAL>(N, !DEV);
+    if (b >= L.G) return;
+    const int G = L.G, lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int cp = t & 1, np = cp ^ 1;
+    char *base = static_cast<char *>(P.scratch);
+    gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + L.lw[cp]));
+    gptr<REAL> lwx = global_ptr(reinterpret_cast<REAL *>(base + L.lw[np]));
+    gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + L.rec[cp]));
+    gptr<REAL> recx = global_ptr(reinterpret_cast<REAL *>(base + L.rec[np]));
+    const double *partc = reinterpret_cast<const double *>(base + L.part[cp]);
+    double *partx = reinterpret_cast<double *>(base + L.part[np]);
+    double *head = reinterpret_cast<double *>(base + L.head);
+
+    double *pw = reinterpret_cast<double *>(smem);                       // [G + 1]
+    double *tab2 = pw + (GRID_MAX_TILES + 1);                            // DEVICE: tile CDF [TILE] + bitmap; REPLAY: coarse [C]
+    double *red = tab2 + (DEV ? TILE + GRID_MAX_TILES / 64 : L.C);
+    double *tabmem = red + (4 * PPT * NW + 16 + PFG_MAX_STAT * NW);
+    GridMath<MODEL, REAL, RNG> mth;
+    mth.t.e2 = tabmem;
+    mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
+    mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
+    if (tab_bytes<REAL, RNG, DEV>() > 0) tab_fill(tabmem, true, tid, NT);
+
+    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = P.stat;
+    const double lam_d = is_filter ? 0.0 : P.lambduh;
+    const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
+    const bool needS_every = is_filter || (lam_d != 1.0);
+    const Consts<REAL> c = make_consts<MODEL, REAL>(P.theta);
+    const gptr<const double> yv = global_ptr(P.y);
+    const gptr<const double> wv = global_ptr(P.weights);
+
+    // ---- prologue: what the whole launch knows about the parents ---------------------------------------------------
+    const GridReduced R = grid_reduce_partials<NT>(partc, G, b, needS_every, DEV, H, mth, pw, red, tid);
+    if (b == 0 && tid == 0) {
+        // log-likelihood of the step these parents were weighted by (buffered_smoother.py:124-126), filter accumulators
+        double ll = head[GH_LL];
+        if (t > 0 && (t - 1) >= t1 && (t - 1) < tL) {
+            const double wprev = wv ? wv[t - 1 - t1] : 1.0;
+            ll += wprev * (R.m + log(R.W / (double)N));
+            head[GH_LL] = ll;
+        }
+        if (P.trace_ll) P.trace_ll[t] = ll;
+        if (is_filter && t > 0) {
+            for (int h = 0; h < H; ++h) head[GH_FILT + h] += R.S[h];
+        }
+    }
+    const double y_t = yv[t];
+    const bool inside = (t >= t1) && (t < tL);
+    const double wt = (inside && wv) ? wv[t - t1] : 1.0;
+    const bool use_stat = inside && (stat != PFG_STAT_NONE);
+
+    REAL lwn[PPT], sn[PPT][H];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        lwn[k] = (REAL)0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) sn[k][h] = (REAL)0;
+    }
+    // one child: parent record -> proposal, weight, statistic -> child record (registers + memory)
+    auto propagate = [&](auto stat_tag, int k, int i, int a, REAL z) {
+        constexpr int STAT = decltype(stat_tag)::value;
+        alignas(16) REAL r[REC];
+        rec_load<REC, REAL>(r, recc + (size_t)a * REC);
+        REAL xp[NS], sp[H], xn[NS], add[H], lwv;
+#pragma unroll
+        for (int d = 0; d < NS; ++d) xp[d] = r[d];
+#pragma unroll
+        for (int h = 0; h < H; ++h) sp[h] = r[NS + h];
+        particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z, xn, lwv, add);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const REAL av = use_stat ? add[h] * (REAL)wt : (REAL)0;
+            const REAL sm = (lam * sp[h] + oml * (REAL)R.S[h]) + av;      // pf.py:175-179 / :78-80
+            sp[h] = is_filter ? av : sm;
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (q == k) {
+                lwn[q] = lwv;
+#pragma unroll
+                for (int h = 0; h < H; ++h) sn[q][h] = sp[h];
+            }
+        }
+        lwx[i] = lwv;
+#pragma unroll
+        for (int d = 0; d < NS; ++d) r[d] = xn[d];
+#pragma unroll
+        for (int h = 0; h < H; ++h) r[NS + h] = sp[h];
+        rec_store<REC, REAL>(recx + (size_t)i * REC, r);
+        if (P.trace_x) {
+            const size_t row = (size_t)(t + 1) * N + i;
+            if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = a;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)xn[d];
+            P.trace_logw[row] = (double)lwv;
+            if (P.trace_stats && !is_filter) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)sp[h];
+            }
+        }
+    };
+    auto step_child = [&](int k, int i, int a, REAL z) {
+        if (stat == PFG_STAT_SCORE) propagate(std::integral_constant<int, PFG_STAT_SCORE>{}, k, i, a, z);
+        else propagate(std::integral_constant<int, PFG_STAT_SUFF>{}, k, i, a, z);
+    };
+
+    LaneRng rng = {};
+    if constexpr (DEV) {
+        // ---- sorted uniforms of this tile's children: the spacings the previous launch totalled, regenerated ----------
+        {
+            const uint4 s = reinterpret_cast<const uint4 *>(base + L.rng)[b * NT + tid];
+            rng.s0 = s.x; rng.s1 = s.y; rng.s2 = s.z; rng.s3 = s.w;
+        }
+        double e[PPT], ce[PPT], u[PPT];
+        int pt[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const float ef = spacing_f32(rng.next());
+            e[k] = (b * TILE + k * NT + tid < N) ? (double)ef : 0.0;
+        }
+        (void)rng.next();                                   // the (N+1)-th spacing's word (tile 0's went into the total)
+        tile_scan<NT, PPT>(e, ce, red, wave, lane);
+        unsigned long long *bitmap = reinterpret_cast<unsigned long long *>(tab2 + TILE);
+        for (int q = tid; q < GRID_MAX_TILES / 64; q += NT) bitmap[q] = 0ull;
+        __syncthreads();
+        int ptmin = G, ptmax = -1;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = b * TILE + k * NT + tid;
+            u[k] = (R.PE_own + ce[k]) * R.invEtot;
+            // parent tile: number of tiles whose CDF ends at or below u (pw[pt + 1] / W <= u)
+            int lo = 0, hi = G - 1;                         // answer in [0, G-1]
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pw[mid + 1] * R.invW <= u[k]) lo = mid + 1; else hi = mid;
+            }
+            pt[k] = lo;
+            if (i < N) {
+                ptmin = lo < ptmin ? lo : ptmin;
+                ptmax = lo > ptmax ? lo : ptmax;
+                atomicOr(&bitmap[lo >> 6], 1ull << (lo & 63));
+                if (P.trace_x && P.rec_ud) P.rec_ud[(size_t)t * N + i] = u[k];
+            }
+        }
+        // children are sorted: the tile's range of parent tiles is [first valid child's, last valid child's]
+        {
+            float fmin = (float)ptmin, fmax = (float)ptmax;
+            fmin = -wave_max(-fmin); fmax = wave_max(fmax);
+            __syncthreads();
+            if (lane == 0) { red[wave] = (double)fmin; red[NW + wave] = (double)fmax; }
+            __syncthreads();
+            double a = red[0], z = red[NW];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { a = red[w] < a ? red[w] : a; z = red[NW + w] > z ? red[NW + w] : z; }
+            ptmin = (int)a; ptmax = (int)z;
+        }
+        REAL zk[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; k += 2) mth.normal_pair(rng.next(), rng.next(), zk[k], zk[k + 1]);
+        if (P.trace_x && P.rec_z) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = b * TILE + k * NT + tid;
+                if (i < N) P.rec_z[(size_t)t * N + i] = (double)zk[k];
+            }
+        }
+        double *cdfl = tab2;                                // [TILE]
+        for (int ptile = ptmin; ptile <= ptmax; ++ptile) {
+            if (!((bitmap[ptile >> 6] >> (ptile & 63)) & 1ull)) continue;       // uniform: no child descends from this tile
+            // ---- rebuild the tile's CDF segment from its log-weights (the same scan its owner totalled) --------------
+            const double mb = partc[ptile];
+            const double sc = uniform_f64(::exp(mb - R.m));
+            const double pw0 = pw[ptile];
+            const int nvalid = (N - ptile * TILE) < TILE ? (N - ptile * TILE) : TILE;
+            double p[PPT], cc[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int j = ptile * TILE + k * NT + tid;
+                p[k] = j < N ? (double)mth.exp_acc((REAL)((double)lwc[j] - mb)) : 0.0;
+            }
+            tile_scan<NT, PPT>(p, cc, red, wave, lane);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) cdfl[k * NT + tid] = (k * NT + tid < nvalid) ? (pw0 + cc[k] * sc) * R.invW : 2.0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = b * TILE + k * NT + tid;
+                if (i < N && pt[k] == ptile) {
+                    int pos = 0;
+#pragma unroll
+                    for (int step = TILE >> 1; step >= 1; step >>= 1) pos += (cdfl[pos + step - 1] <= u[k]) ? step : 0;
+                    pos = pos < nvalid - 1 ? pos : nvalid - 1;
+                    step_child(k, i, ptile * TILE + pos, zk[k]);
+                }
+            }
+            // (the next rebuild's tile_scan starts with a barrier: cdfl is not overwritten while it is searched)
+        }
+    } else {
+        // ---- REPLAY: the reference's uniforms in index order against the reference's CDF (pfg_grid_cdf_kernel) --------
+        const gptr<const double> cdf = global_ptr(reinterpret_cast<const double *>(base + L.cdf));
+        const gptr<const double> coarse_g = global_ptr(reinterpret_cast<const double *>(base + L.coarse));
+        double *coarse = tab2;
+        const int C = L.C, S = L.S;
+        for (int q = tid; q < C; q += NT) coarse[q] = coarse_g[q];
+        __syncthreads();
+        const gptr<const double> uv = global_ptr(P.u), zv = global_ptr(P.z);
+        double tie = 1.0;
+        int cpow = 1;
+        while (cpow < C) cpow <<= 1;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = b * TILE + k * NT + tid;
+            if (i < N) {
+                const double u = uv[(size_t)t * N + i];
+                const REAL z = (REAL)zv[(size_t)t * N + i];
+                // block: number of coarse entries (= last CDF entry of each block of S) at or below u, at most C - 1
+                int cb = 0;
+                for (int step = cpow >> 1; step >= 1; step >>= 1) {
+                    const int q = cb + step - 1;
+                    cb += (q < C - 1 && coarse[q] <= u) ? step : 0;
+                }
+                cb = cb < C - 1 ? cb : C - 1;
+                const int j0 = cb * S;
+                const int nb = (N - j0) < S ? (N - j0) : S;
+                int pos = 0;
+                for (int step = S >> 1; step >= 1; step >>= 1) {
+                    const int q = pos + step - 1;
+                    pos += (q < nb && cdf[j0 + q] <= u) ? step : 0;
+                }
+                int a = j0 + pos;
+                a = a < N - 1 ? a : N - 1;
+                {
+                    const double hi = cdf[a] - u;
+                    const double lo = a > 0 ? u - cdf[a - 1] : 1.0;
+                    const double mg = hi < lo ? hi : lo;
+                    tie = mg < tie ? mg : tie;
+                }
+                step_child(k, i, a, z);
+            }
+        }
+        tie = -wave_max(-tie);
+        if (lane == 0) atomic_min_pos_f64(&head[GH_TIE], tie < 0.0 ? 0.0 : tie);
+    }
+
+    // ---- epilogue: partials of the children for the next launch -------------------------------------------------------
+    const bool needS_next = needS_every || (t + 1 == T);
+    grid_tile_partials<NT, H, REAL>(partx, G, b, N, lwn, sn, needS_next, mth, red, tid);
+    if constexpr (DEV) {
+        if (t + 1 < T) grid_tile_spacings<NT>(partx, G, b, N, rng, red, tid);
+        reinterpret_cast<uint4 *>(base + L.rng)[b * NT + tid] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// finish (after the last step): W_T, the mean statistic (average_statistic, buffered_smoother.py:151-154), the last
+// log-likelihood term; final particles on request.  One workgroup per window reduces, the grid copies.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODEL, typename REAL, int RNG, int NT>
+__global__ __launch_bounds__(NT) void pfg_grid_finish_kernel(const pfg_dev_problem *__restrict__ probs) {
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT, NW = NT / WAVE;
+    constexpr int REC = mem_rec_len<MODEL, REAL>();
+    extern __shared__ __align__(16) unsigned char smem[];
+    const pfg_dev_problem &P = probs[blockIdx.y];
+    const int N = P.N, T = P.T, b = blockIdx.x, tid = threadIdx.x;
+    const GridLayout L = grid_layout<MODEL, REAL>(N, RNG == PFG_RNG_REPLAY);
+    if (b >= L.G) return;
+    const int cp = T & 1;
+    char *base = static_cast<char *>(P.scratch);
+    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
+    if (b == 0) {
+        double *pw = reinterpret_cast<double *>(smem);
+        double *red = pw + (GRID_MAX_TILES + 1);
+        const double *partc = reinterpret_cast<const double *>(base + L.part[cp]);
+        double *head = reinterpret_cast<double *>(base + L.head);
+        const Math<double, false> mth = {};
+        const GridReduced R = grid_reduce_partials<NT>(partc, L.G, 0, true, false, H, mth, pw, red, tid);
+        if (tid == 0) {
+            double ll = head[GH_LL];
+            if (T > 0 && (T - 1) >= P.t1 && (T - 1) < P.tL) {
+                const double wprev = P.weights ? P.weights[T - 1 - P.t1] : 1.0;
+                ll += wprev * (R.m + log(R.W / (double)N));
+            }
+            if (P.trace_ll) P.trace_ll[T] = ll;
+            if (P.out) {
+                for (int h = 0; h < PFG_MAX_STAT; ++h) P.out[h] = 0.0;
+                for (int h = 0; h < H; ++h) P.out[h] = is_filter ? head[GH_FILT + h] + (T > 0 ? R.S[h] : 0.0) : R.S[h];
+                P.out[4] = ll; P.out[5] = R.W; P.out[6] = R.m; P.out[7] = head[GH_TIE];
+            }
+        }
+    }
+    if (P.final_x) {
+        gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + L.lw[cp]));
+        gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + L.rec[cp]));
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = b * TILE + k * NT + tid;
+            if (i < N) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)recc[(size_t)i * REC + d];
+                if (P.final_logw) P.final_logw[i] = (double)lwc[i];
+                if (P.final_stats && !is_filter) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)recc[(size_t)i * REC + NS + h];
+                }
+            }
+        }
+    }
+    (void)NW;
+}
+
+}  // namespace pfg

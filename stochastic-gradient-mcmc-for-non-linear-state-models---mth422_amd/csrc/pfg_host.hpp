@@ -88,10 +88,15 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // variant ids below zero: kernels other than the LDS-resident table entries
 constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
 constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
+constexpr int kVariantGrid = -7;    // whole-GPU window for N above the one-workgroup kernels' maximum (pfg_grid_kernel.hpp)
 
 // Launch of every kernel of one (model, proposal kernel, generator): defined (and explicitly
 // instantiated) in pfg_inst_*.hip via pfg_launch.hpp, declared here for the dispatcher in pfgrad.hip.
 template <int MODEL, int KERNEL, int RNG>
 int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced);
+
+// the whole-GPU window of one (model, kernel, generator): T_max + 2 (REPLAY: 2 T_max + 2) launches, see pfg_launch.hpp
+template <int MODEL, int KERNEL, int RNG>
+int launch_grid_mkr(pfg_ctx *ctx, int dtype, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st);
 
 }  // namespace pfg_host

@@ -275,6 +275,25 @@ __device__ __forceinline__ double exp_tab(double x, const double *__restrict__ e
 #endif
 }
 
+// the <= 2 ulp form whatever the unit's flags (the whole-GPU window builds its resampling CDF with it also in the
+// device-generator units: at N = 10^5 .. 10^6 the 3e-12 of the cubic form above would flip ancestors between the kernel
+// and the oracle that replays its recorded draws -- 2 N^2 delta per step)
+__device__ __forceinline__ double exp_tab_acc(double x, const double *__restrict__ e2) {
+    static_assert(TAB_E2 == 128, "exp_tab_acc uses the 128-entry table");
+    x = fmax(x, -1000.0);
+    const double kd = rint(x * 184.6649652337873);                  // 128/ln2
+    const int k = (int)kd;
+    double r = fma(kd, -0.00541521234663378, x);                     // ln2/128, 32-bit head
+    r = fma(kd, -1.4907929134926466e-12, r);                         //          tail
+    const double t = e2[k & 127];
+    double p = fma(r, 0.008333333333333333, 0.041666666666666664);   // expm1(r), |r| <= ln2/256
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = p * r;
+    p = fma(p, r, r);
+    return ldexp(fma(t, p, t), k >> 7);
+}
+
 // log(x) for finite x > 0 in the normal range
 __device__ __forceinline__ double log_tab(double x, const double2 *__restrict__ lg) {
     const uint32_t hi = (uint32_t)__double2hiint(x);
@@ -313,6 +332,7 @@ template <typename REAL, bool TAB> struct Math;
 template <> struct Math<double, true> {
     TabF64 t;
     __device__ __forceinline__ double exp(double x) const { return exp_tab(x, t.e2); }
+    __device__ __forceinline__ double exp_acc(double x) const { return exp_tab_acc(x, t.e2); }
 #ifdef PFG_FAST_ALGEBRA
     __device__ __forceinline__ double exp_finite(double x) const { return exp_tab<true>(x, t.e2); }
 #else
@@ -347,6 +367,7 @@ template <> struct Math<double, true> {
 template <> struct Math<double, false> {
     TabF64 t;
     __device__ __forceinline__ double exp(double x) const { return ::exp(x); }
+    __device__ __forceinline__ double exp_acc(double x) const { return ::exp(x); }
     __device__ __forceinline__ double exp_finite(double x) const { return ::exp(x); }
     __device__ __forceinline__ double log(double x) const { return ::log(x); }
     __device__ __forceinline__ double sqrt(double x) const { return ::sqrt(x); }
@@ -368,6 +389,7 @@ template <> struct Math<double, false> {
 template <bool TAB> struct Math<float, TAB> {
     TabF64 t;
     __device__ __forceinline__ float exp(float x) const { return __expf(x); }
+    __device__ __forceinline__ float exp_acc(float x) const { return __expf(x); }
     __device__ __forceinline__ float exp_finite(float x) const { return __expf(x); }
     __device__ __forceinline__ float log(float x) const { return __logf(x); }
     __device__ __forceinline__ float sqrt(float x) const { return sqrtf(x); }

@@ -22,6 +22,23 @@ extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE
 extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
 extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
 
+extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+
+template <int MODEL, int KERNEL>
+int launch_grid_mk(pfg_ctx *ctx, int dtype, int rng, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+    if (rng == PFG_RNG_REPLAY) return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, n_max, t_max, B, dp, st);
+    return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, n_max, t_max, B, dp, st);
+}
+
 template <int MODEL, int KERNEL>
 int launch_mk(pfg_ctx *ctx, int dtype, int rng, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
     if (rng == PFG_RNG_REPLAY) return launch_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, v, n_max, B, dp, st, traced);
@@ -120,7 +137,19 @@ int pick_variant(int model, int dtype, int rng, int n_max, int batch = 1 << 30) 
         lds_bytes(model, dtype, rng, kVariants[kLds4096Variant], n_max) <= kLdsLimit)
         return kLds4096Variant;
     if (n_max <= pfg::MEM_MAX_N) return kVariantMem;
+    if (n_max <= pfg::GRID_MAX_N) return kVariantGrid;     // one window over the whole GPU (pfg_grid_kernel.hpp)
     return -1;
+}
+
+size_t grid_scratch_bytes(int model, int dtype, int rng, int N) {
+    const bool rp = rng == PFG_RNG_REPLAY;
+    if (dtype == PFG_F64)
+        return model == PFG_MODEL_SVM ? pfg::grid_layout<PFG_MODEL_SVM, double>(N, rp).bytes
+               : model == PFG_MODEL_GARCH ? pfg::grid_layout<PFG_MODEL_GARCH, double>(N, rp).bytes
+                                          : pfg::grid_layout<PFG_MODEL_LGSSM, double>(N, rp).bytes;
+    return model == PFG_MODEL_SVM ? pfg::grid_layout<PFG_MODEL_SVM, float>(N, rp).bytes
+           : model == PFG_MODEL_GARCH ? pfg::grid_layout<PFG_MODEL_GARCH, float>(N, rp).bytes
+                                      : pfg::grid_layout<PFG_MODEL_LGSSM, float>(N, rp).bytes;
 }
 
 size_t scratch_bytes(int model, int dtype, int N, bool paris = false) {
@@ -156,7 +185,11 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
             : pick_variant(model, dtype, rng, n_max, B);
     if (v == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
-                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
+                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::GRID_MAX_N));
+    if (v == kVariantGrid)
+        return fail(ctx, PFG_ERR_UNSUPPORTED,
+                    "N = " + std::to_string(n_max) + " > " + std::to_string(pfg::MEM_MAX_N) +
+                    " runs as a whole-GPU window, one launch per timestep: use pfg_launch_device_grid (it needs T_max)");
     // N > 1024 with the device generator: the fast large-N kernel, unless the statistic needs the
     // general one (predictive) or PFGRAD_VARIANT=mem1024 asks for it (A/B timing, tests)
     if (v == kVariantMem && rng == PFG_RNG_DEVICE && !force_mem) {
@@ -177,6 +210,27 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     }
     if (kernel == PFG_KERNEL_PRIOR) return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
     return launch_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, v, n_max, B, dp, st, traced);
+}
+
+// whole-GPU windows (N above the one-workgroup kernels' maximum, or forced): NEMETH / FILTER with the score,
+// sufficient or no statistic
+int dispatch_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int t_max, int B,
+                  const pfg_dev_problem *dp, hipStream_t st) {
+    int rc = check_combo(ctx, model, kernel, dtype, rng);
+    if (rc) return rc;
+    if (B <= 0) return PFG_OK;
+    if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
+    if (t_max < 0) return fail(ctx, PFG_ERR_INVALID, "T_max must be >= 0");
+    if (B > 65535) return fail(ctx, PFG_ERR_INVALID, "at most 65535 whole-GPU windows per launch");
+    ctx->last_variant = pfg::grid_nt(n_max) == 512 ? "grid512x4" : "grid256x4";
+    ctx->last_traced = true;
+    if (model == PFG_MODEL_SVM) return launch_grid_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+    if (model == PFG_MODEL_GARCH) {
+        if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+        return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+    }
+    if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+    return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st);
 }
 
 // ---- SGLD update for resident chains ---------------------------------------------------
@@ -462,6 +516,7 @@ int64_t pfg_scratch_bytes(int model, int dtype, int rng, int N) {
     const int v = pick_variant(model, dtype, rng, N);
     if (v >= 0) return 0;
     if (v == kVariantMem) return (int64_t)((scratch_bytes(model, dtype, N) + 255) / 256 * 256);
+    if (v == kVariantGrid) return (int64_t)grid_scratch_bytes(model, dtype, rng, N);
     return -1;
 }
 
@@ -472,6 +527,7 @@ const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_ma
         const char *force = std::getenv("PFGRAD_VARIANT");
         if (!(force && !std::strcmp(force, "mem1024"))) return n_max <= 4096 ? "big4096" : "big16384";
     }
+    if (v == kVariantGrid) return pfg::grid_nt(n_max) == 512 ? "grid512x4" : "grid256x4";
     return v == kVariantMem ? "mem1024" : (v < 0 ? "none" : kVariants[v].tag);
 }
 
@@ -501,6 +557,14 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother, false, false);
+}
+
+int pfg_launch_device_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int T_max, int B,
+                           const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid: dev_probs is NULL");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch_grid(ctx, model, kernel, dtype, rng, n_max, T_max, B, dev_probs, (hipStream_t)hip_stream);
 }
 
 int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum, const double *outs,
@@ -752,16 +816,36 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
     const bool predictive = ps[0].stat == PFG_STAT_PREDICTIVE;   // large-N kernel only (any N)
     const bool n2 = ps[0].smoother == PFG_SMOOTHER_POYIADJIS_N2;
-    const int variant = paris ? kVariantParis : sysres ? kVariantSystematic : n2 ? kVariantN2
-                        : predictive ? kVariantMem : pick_variant(model, dtype, rng, n_max);
+    int variant = paris ? kVariantParis : sysres ? kVariantSystematic : n2 ? kVariantN2
+                  : predictive ? kVariantMem : pick_variant(model, dtype, rng, n_max);
     if (variant == -1)
         return fail(ctx, PFG_ERR_UNSUPPORTED,
-                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::MEM_MAX_N));
+                    "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::GRID_MAX_N));
+    // PFGRAD_VARIANT=grid: the whole-GPU window also where a one-workgroup kernel would serve (tests, A/B timing)
+    if (variant != kVariantGrid && !paris && !sysres && !n2 && !predictive) {
+        const char *force = std::getenv("PFGRAD_VARIANT");
+        if (force && !std::strcmp(force, "grid")) variant = kVariantGrid;
+    }
+    int t_max = 0;
+    if (variant == kVariantGrid) {
+        for (int b = 0; b < B; ++b) {
+            const pfg_problem &q = ps[b];
+            const std::string id = "problem " + std::to_string(b) + ": ";
+            if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_FILTER)
+                return fail(ctx, PFG_ERR_UNSUPPORTED, id + "N > " + std::to_string(pfg::MEM_MAX_N) + " is built for pf = 'poyiadjis_N' | 'nemeth' | 'filter'");
+            if (q.elementwise) return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for N <= " + std::to_string(pfg::MEM_MAX_N));
+            if (pfg::grid_nt(q.N) != pfg::grid_nt(n_max))
+                return fail(ctx, PFG_ERR_INVALID, id + "whole-GPU windows of one batch must all have N <= 262144 or all N > 262144");
+            t_max = q.T > t_max ? q.T : t_max;
+        }
+    }
     size_t n_scratch = 0;                  // bytes; every window of the batch gets n_max-sized state
     const size_t pred_each = predictive ? ((size_t)n_max * PFG_MAX_PRED * (dtype == PFG_F64 ? 8 : 4) + 255) / 256 * 256 : 0;
     const bool paris_mem = (paris || n2) && n_max > 1024;       // the large-N kernel's PaRIS instantiation (also its O(N^2) sweep)
     const size_t scratch_each = (scratch_bytes(model, dtype, n_max, paris_mem) + 255) / 256 * 256 + pred_each;
     if (variant == kVariantMem || paris_mem) n_scratch = scratch_each * (size_t)B;
+    const size_t grid_each = variant == kVariantGrid ? grid_scratch_bytes(model, dtype, rng, n_max) : 0;
+    if (variant == kVariantGrid) n_scratch = grid_each * (size_t)B;
 
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     PFG_HIP(ctx, ctx->in.ensure(n_in * 8));
@@ -912,7 +996,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             std::memcpy(&slot, &q.step, sizeof slot);
             d.step_ctr = reinterpret_cast<const uint64_t *>(put(&slot, 1));
         }
-        d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + scratch_each * (size_t)b)
+        d.scratch = n_scratch ? static_cast<void *>(static_cast<char *>(ctx->scratch.ptr) + (variant == kVariantGrid ? grid_each : scratch_each) * (size_t)b)
                               : nullptr;
         if (predictive) d.pred_scratch = static_cast<char *>(d.scratch) + (scratch_each - pred_each);
         d.prior_mean = q.prior_mean; d.prior_var = q.prior_var; d.lambduh = q.lambduh;
@@ -928,10 +1012,13 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     PFG_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->h_desc.data(), (size_t)B * sizeof(pfg_dev_problem),
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
-    rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
-                  ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC
-                               : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
-                  predictive, traced);
+    if (variant == kVariantGrid)
+        rc = dispatch_grid(ctx, model, kernel, dtype, rng, n_max, t_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr), ctx->stream);
+    else
+        rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
+                      ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC
+                                   : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
+                      predictive, traced);
     if (rc) return rc;
     for (int b = 0; b < B; ++b) {
         if (!ps[b].elementwise) continue;

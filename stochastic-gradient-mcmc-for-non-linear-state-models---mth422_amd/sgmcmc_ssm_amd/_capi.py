@@ -132,7 +132,7 @@ EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_l
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
            "pfg_last_variant", "pfg_legacy_streams", "pfg_host_register", "pfg_host_unregister",
-           "pfg_launch_device_traced", "pfg_last_traced")
+           "pfg_launch_device_traced", "pfg_last_traced", "pfg_launch_device_grid")
 
 _lib = None
 
@@ -196,6 +196,8 @@ def load_library():
     lib.pfg_launch_device_smoother.restype = C.c_int
     lib.pfg_launch_device_traced.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
     lib.pfg_launch_device_traced.restype = C.c_int
+    lib.pfg_launch_device_grid.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    lib.pfg_launch_device_grid.restype = C.c_int
     lib.pfg_last_traced.argtypes = [C.c_void_p]
     lib.pfg_last_traced.restype = C.c_int
     lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -535,6 +537,12 @@ class Context:
 
     def last_traced(self):
         return bool(self.lib.pfg_last_traced(self.handle))
+
+    def launch_device_grid(self, model, kernel, dtype, rng, n_max, T_max, B, dev_probs_ptr, stream_ptr=0):
+        """Whole-GPU windows (N > 16384: one launch per timestep, pfg_launch_device_grid); T_max = the largest T."""
+        self._check(self.lib.pfg_launch_device_grid(
+            self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max), int(T_max), int(B),
+            C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
 
     def launch_device(self, model, kernel, dtype, rng, n_max, B, dev_probs_ptr, stream_ptr=0):
         """stream_ptr: a hipStream_t handle used as is (0 = HIP's default stream, which is also

@@ -49,7 +49,7 @@ _SPECULATE_MIN = 200000        # N*T from which the next stream is prefetched on
                                # and joining the thread costs more than the ~4 ns per draw it hides: measured
                                # 0.49 -> 0.79 ms per step at N*T = 24000, 8.5 -> 5.6 ms at 1e6)
 _stream_pool = {}
-_STREAM_POOL_MAX_BYTES = 512 << 20
+_STREAM_POOL_MAX_BYTES = 2048 << 20     # a T = 48, N = 10^6 window (the reference's bias experiments) is 2 x 384 MB
 # the prefetch worker (speculation) and the caller's thread both take and return buffers: one lock for the pool and
 # the page-locked bookkeeping below
 import threading
@@ -60,7 +60,7 @@ _pool_lock = threading.RLock()
 # process -- registered pages must never go back to the allocator -- so that pfg_run_batch stages them by DMA
 # from where the generator wrote them instead of copying 16 MB into its own pinned arena first.
 _PIN_MIN_BYTES = 1 << 20
-_PIN_MAX_BYTES = 256 << 20
+_PIN_MAX_BYTES = 2048 << 20
 _pinned = []                   # (u, z) pairs kept alive for good
 _pinned_bytes = 0
 

@@ -5,7 +5,7 @@ travels to the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld,eurus,theta_grid}.npz.  Fixtures are data only:
+Writes tests/golden/{pf_trace,pf_window,host,sampler,ksd,paris,latent,predictive,n2,sgrld,eurus,theta_grid,giant}.npz.  Fixtures are data only:
 inputs (observations, raw parameters, seeds, window bounds, weights) and the
 reference's outputs.  Random streams are NOT stored: NumPy's legacy MT19937 stream is
 frozen, so tests regenerate them from the seed.
@@ -820,6 +820,62 @@ def make_eurus_fixtures():
 # Cholesky factors of 0.1 and 10, GARCH persistence phi -> 0.999 and mixing lambduh near 0 / 1
 # (models/garch/kernels.py:136-180).  Data are generated by the reference from the same parameters.
 # ----------------------------------------------------------------------------------------------------
+def make_giant_fixtures():
+    """The reference's OWN giant-N calls of the hot-path entry: the bias experiments take the mean of ten
+    helper.pf_gradient_estimate(pf='poyiadjis_N', N=1000000) runs on a buffered 48-step window as ground truth
+    (nonlinear_ssm_pf_experiment_scripts/gradient_error_fig_scripts/svm_grad_compare.py:58-82: T = 100, L = 16,
+    t0 = (T + L) // 2, buffer_size = L; garch_grad_compare.py:66-93: buffer_size = 12).  Inputs + outputs only (gradient,
+    log-likelihood, the NEXT np.random draw after the call = how far it advanced the generator); N = 10^5 takes ~2 s,
+    N = 10^6 ~40 s per call here."""
+    out, meta = {}, []
+    helpers = {"svm": SVMHelper, "garch": GARCHHelper, "lgssm": LGSSMHelper}
+    cases = [("svm", 100000, 16, "poyiadjis_N", None, dict()),
+             ("svm", 1000000, 16, "poyiadjis_N", None, dict()),
+             ("garch", 100000, 12, "poyiadjis_N", None, dict()),
+             ("garch", 1000000, 12, "poyiadjis_N", None, dict()),
+             ("lgssm", 100000, 8, "nemeth", None, dict()),
+             ("lgssm", 300000, 4, "nemeth", "prior", dict(lambduh=0.9)),
+             ("svm", 50000, 8, "filter", None, dict())]
+    T, L = 100, 16
+    for ci, (model, N, B, pf, kernel, kw) in enumerate(cases):
+        cfg = MODEL_SETUP[model]
+        p = cfg["params"]()
+        np.random.seed(12345)
+        data = cfg["gen"](T=T, parameters=p)
+        t0 = (T + L) // 2
+        y = data["observations"][t0 - B:t0 + L + B]
+        fm = data["initial_message"] if model != "garch" else None
+        helper = helpers[model](forward_message=fm, **p.dim) if model != "garch" else helpers[model](**p.dim)
+        weights = None if ci % 2 == 0 else 1.0 + 0.5 * np.arange(L)
+        seed = 4100 + ci
+        key = "g{0}".format(len(meta))
+        if pf != "filter":
+            np.random.seed(seed)
+            g = helper.pf_gradient_estimate(observations=y, parameters=p, subsequence_start=B, subsequence_end=L + B,
+                                            weights=weights, pf=pf, N=N, kernel=kernel, **kw)
+            out[key + "/grad"] = as_vec(model, g)
+            out[key + "/next_draw"] = np.float64(np.random.random_sample())
+        if N <= 100000:
+            np.random.seed(seed)
+            ll = helper.pf_loglikelihood_estimate(observations=y, parameters=p, subsequence_start=B, subsequence_end=L + B,
+                                                  weights=weights, pf=pf, N=N, kernel=kernel, **kw)
+            out[key + "/loglik"] = np.float64(ll)
+            out[key + "/next_draw_loglik"] = np.float64(np.random.random_sample())
+        meta.append(dict(key=key, model=model, kernel=kernel, N=N, T=int(y.shape[0]), t1=B, tL=L + B, pf=pf, seed=seed, kwargs=kw,
+                         has_forward_message=fm is not None, has_grad=pf != "filter", has_loglik=N <= 100000))
+        out[key + "/y"] = y.reshape(-1)
+        out[key + "/theta"] = theta_of(model, p)
+        if weights is not None:
+            out[key + "/weights"] = weights
+        if fm is not None:
+            out[key + "/fm_precision"] = np.asarray(fm["precision"], dtype=float).reshape(-1)
+            out[key + "/fm_mean_precision"] = np.asarray(fm["mean_precision"], dtype=float).reshape(-1)
+        print("giant", key, model, N, pf, out.get(key + "/grad"), out.get(key + "/loglik"), flush=True)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "giant.npz"), **out)
+    print("giant:", len(meta), "cases")
+
+
 def garch_raw(mu, phi, lam, LRinv):
     logit = lambda q: np.log(q / (1.0 - q))
     return GARCHParameters(log_mu=np.log(mu), logit_phi=logit(phi), logit_lambduh=logit(lam), LRinv=np.eye(1) * LRinv)
@@ -953,6 +1009,8 @@ if __name__ == "__main__":
         make_paris_seed_fixtures()
     if only in ("", "n2_large"):
         make_n2_large_fixtures()
+    if only in ("", "giant"):
+        make_giant_fixtures()
     for f in ("pf_trace.npz", "pf_window.npz", "host.npz", "sampler.npz", "ksd.npz", "paris.npz", "latent.npz", "predictive.npz", "theta_grid.npz"):
         if os.path.exists(os.path.join(HERE, f)):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
