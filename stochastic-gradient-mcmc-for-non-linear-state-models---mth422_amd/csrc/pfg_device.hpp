@@ -20,4 +20,5 @@
 #include "pfg_mem_kernel.hpp"    // N <= 16384: general large-N kernel
 #include "pfg_big_kernel.hpp"    // N <= 16384: device-generator fast path
 #include "pfg_grid_kernel.hpp"   // N <= 2^22: one window over the whole GPU, one launch per timestep
+#include "pfg_grid_dev_kernel.hpp"   // ... its device-generator timestep (the throughput path)
 #include "pfg_grid_cdf.hpp"      // ... its REPLAY CDF: NumPy's sequential cumsum, bit for bit

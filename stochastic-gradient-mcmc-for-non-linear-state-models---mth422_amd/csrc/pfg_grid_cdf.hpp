@@ -81,8 +81,8 @@ __global__ __launch_bounds__(CDF_NT) void pfg_grid_cdf_kernel(const pfg_dev_prob
     const int N = P.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const GridLayout L = grid_layout<MODEL, REAL>(N, true);
     char *base = static_cast<char *>(P.scratch);
-    gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + L.lw[t & 1]));
-    const double *partc = reinterpret_cast<const double *>(base + L.part[t & 1]);
+    gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.lw, t & 1)));
+    const double *partc = reinterpret_cast<const double *>(base + grid_sel(L.part, t & 1));
     double *head = reinterpret_cast<double *>(base + L.head);
     gptr<double> A = global_ptr(reinterpret_cast<double *>(base + L.cdf));            // p -> Q (as bits) -> cdf, in place
     gptr<unsigned long long> AQ = (gptr<unsigned long long>)A;

@@ -6,7 +6,7 @@
 // particle_filters/pf.py:7-38 has no N limit): there ONE window is 80 MB of state per timestep, the byte roofline of
 // SURVEY 8(d) is the real bound, and the particle axis of the window is what has to be spread over the 256 CUs.
 //
-// Structure: the particle axis is cut into tiles of TILE = NT * GRID_PPT particles, one workgroup per tile; one kernel
+// Structure: the particle axis is cut into tiles of TILE = 256 * PPT particles (PPT = 4 | 8), one workgroup per tile; one kernel
 // launch per timestep (a dependent launch boundary is ~1.5 us, a software grid barrier 4-7 us, and a boundary also
 // makes the other XCDs' L2 see this step's children).  State lives in a per-window HBM scratch:
 //     lw[2][N]            log-weights, ping-pong by timestep parity
@@ -39,19 +39,39 @@
 namespace pfg {
 
 constexpr int GRID_MAX_N = 1 << 22;
-constexpr int GRID_PPT = 4;
+constexpr int GRID_SMALL_N = 1 << 20;          // up to here: 256 threads x 4 children (1024-particle tiles)
+#ifndef PFG_GRID_BIG_NT
+#define PFG_GRID_BIG_NT 512
+#endif
+#ifndef PFG_GRID_BIG_PPT
+#define PFG_GRID_BIG_PPT 4
+#endif
+constexpr int GRID_BIG_NT = PFG_GRID_BIG_NT, GRID_BIG_PPT = PFG_GRID_BIG_PPT;      // above: 2048-particle tiles
+static_assert(GRID_BIG_NT * GRID_BIG_PPT == 2048, "GRID_MAX_N / 2048 tiles is what the tile tables are sized for");
 constexpr int GRID_MAX_TILES = 2048;
 constexpr int GRID_COARSE_MAX = 16384;
 constexpr int GRID_HEAD_DOUBLES = 32;
 // head slots
 constexpr int GH_LL = 0, GH_FILT = 1 /* ..4 */, GH_TIE = 5, GH_WALK = 6, GH_M = 7, GH_W = 8, GH_S = 9 /* ..12 */, GH_ERR = 13;
 
-__host__ __device__ inline int grid_nt(int N) { return N <= (1 << 18) ? 256 : 512; }
+// Tile classes.  Up to 2^19 particles: 256 threads x 4 children = 1024-particle tiles -- a timestep is one short round of
+// workgroups, bound by the length of a workgroup's dependency chain.  Above: 2048-particle tiles, so that the per-tile lists
+// every workgroup reduces (all tiles' partials) and searches are half as long.
+__host__ __device__ inline int grid_nt(int N) { return N <= GRID_SMALL_N ? 256 : GRID_BIG_NT; }
+__host__ __device__ inline int grid_ppt(int N) { return N <= GRID_SMALL_N ? 4 : GRID_BIG_PPT; }
+// tiles per thread in the reduction over the tile partials, at most (loop bounds of the step kernels)
+template <int NT, int PPT> __host__ __device__ constexpr int grid_kmax() {
+    return ((NT * PPT <= 1024 ? GRID_SMALL_N : GRID_MAX_N) / (NT * PPT) + NT - 1) / NT;
+}
 
 struct GridLayout {
-    int N, NT, TILE, G, C, S, PSTRIDE;          // C coarse entries of stride S (REPLAY); PSTRIDE doubles per partial parity
-    size_t lw[2], rec[2], part[2], rng, head, cdf, coarse, walk_i, walk_p, walk_q, walk_s, bytes;
+    int N, NT, PPT, TILE, G, C, S, PSTRIDE;          // C coarse entries of stride S (REPLAY); PSTRIDE doubles per partial parity
+    size_t lw[2], rec[2], part[2], rng, head, cdf, coarse, walk_i, walk_p, walk_q, walk_s, cs[2], tab, consts, bytes;
 };
+
+// a ping-pong offset by runtime parity WITHOUT indexing the struct's arrays (dynamic indexing would put the whole
+// layout struct into scratch memory)
+__host__ __device__ inline size_t grid_sel(const size_t (&a)[2], int q) { return q ? a[1] : a[0]; }
 
 // partials of one parity: pm[G] | pW[G] | pE[G] | pS[4][G] | extra[8]  (extra[0] = the (N+1)-th spacing)
 __host__ __device__ inline size_t grid_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -61,7 +81,8 @@ __host__ __device__ inline GridLayout grid_layout(int N, bool replay) {
     GridLayout L;
     L.N = N;
     L.NT = grid_nt(N);
-    L.TILE = L.NT * GRID_PPT;
+    L.PPT = grid_ppt(N);
+    L.TILE = L.NT * L.PPT;
     L.G = (N + L.TILE - 1) / L.TILE;
     int S = 64;
     while ((N + S - 1) / S > GRID_COARSE_MAX) S <<= 1;
@@ -75,7 +96,14 @@ __host__ __device__ inline GridLayout grid_layout(int N, bool replay) {
     for (int q = 0; q < 2; ++q) { L.part[q] = o; o = grid_align(o + (size_t)L.PSTRIDE * 8); }
     L.rng = o; o = grid_align(o + (size_t)L.G * L.NT * 16);
     L.head = o; o = grid_align(o + GRID_HEAD_DOUBLES * 8);
-    L.cdf = L.coarse = L.walk_i = L.walk_p = L.walk_q = L.walk_s = o;
+    L.cdf = L.coarse = L.walk_i = L.walk_p = L.walk_q = L.walk_s = L.cs[0] = L.cs[1] = L.tab = L.consts = o;
+    if (!replay) {
+        // device generator: the tile-local inclusive scans of exp(lw - m_b) (what the next launch searches; written
+        // instead of the log-weights on the hot path), and the math tables every launch loads into LDS
+        for (int q = 0; q < 2; ++q) { L.cs[q] = o; o = grid_align(o + (size_t)N * 8); }
+        L.tab = o; o = grid_align(o + (size_t)(TAB_E2_ACC + 2 * TAB_LG) * 8);
+        L.consts = o; o = grid_align(o + sizeof(Consts<double>));      // model constants, derived once per window
+    }
     if (replay) {
         L.cdf = o; o = grid_align(o + (size_t)N * 8);
         L.coarse = o; o = grid_align(o + (size_t)L.C * 8);
@@ -217,22 +245,22 @@ __device__ __forceinline__ void atomic_min_pos_f64(double *addr, double v) {
 template <int MODEL, typename REAL, int RNG>
 using GridMath = Math<REAL, (RNG == PFG_RNG_DEVICE)>;
 
-template <int NT, typename REAL, int RNG>
+template <int NT, int PPT, typename REAL, int RNG>
 __host__ __device__ constexpr size_t grid_step_lds_bytes(int C) {
     // pw [G+1 <= 2049] | tile CDF [TILE] or coarse [C] | red [4 PPT NW + 16] | tables
     return (size_t)(GRID_MAX_TILES + 1) * 8 +
-           (RNG == PFG_RNG_DEVICE ? (size_t)NT * GRID_PPT * 8 + (size_t)GRID_MAX_TILES / 8 : (size_t)C * 8) +
-           (size_t)(4 * GRID_PPT * (NT / WAVE) + 16 + PFG_MAX_STAT * (NT / WAVE)) * 8 + tab_bytes<REAL, RNG, (RNG == PFG_RNG_DEVICE)>();
+           (size_t)C * 8 +
+           (size_t)(4 * PPT * (NT / WAVE) + 16 + PFG_MAX_STAT * (NT / WAVE)) * 8 + tab_bytes<REAL, RNG, (RNG == PFG_RNG_DEVICE)>();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Epilogue shared by the init and step kernels: the partials of the particles this workgroup has just created (their
 // log-weights in lwn[], statistics in sn[][]), for the launch that will resample them.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NT, int H, typename REAL, typename MATH>
-__device__ __forceinline__ void grid_tile_partials(double *__restrict__ part, int G, int b, int N, const REAL (&lwn)[GRID_PPT],
-                                                   const REAL (&sn)[GRID_PPT][H], bool needS, const MATH &mth, double *red, int tid) {
-    constexpr int NW = NT / WAVE, PPT = GRID_PPT;
+template <int NT, int PPT, int H, typename REAL, typename MATH>
+__device__ __forceinline__ void grid_tile_partials(double *__restrict__ part, int G, int b, int N, const REAL (&lwn)[PPT],
+                                                   const REAL (&sn)[PPT][H], bool needS, const MATH &mth, double *red, int tid) {
+    constexpr int NW = NT / WAVE;
     const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     double ml = -INFINITY;
 #pragma unroll
@@ -262,38 +290,125 @@ __device__ __forceinline__ void grid_tile_partials(double *__restrict__ part, in
     }
 }
 
-// spacings of the NEXT resampling step for this tile's children (device generator): the tile total, from a COPY of the
-// lane generator -- the step kernel regenerates the same words from the saved state
-template <int NT>
-__device__ __forceinline__ void grid_tile_spacings(double *__restrict__ part, int G, int b, int N, LaneRng rng, double *red, int tid) {
-    constexpr int NW = NT / WAVE, PPT = GRID_PPT;
-    const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-    double e[PPT], c[PPT];
+// ------------------------------------------------------------------------------------------------------------------
+// Device-generator epilogue (init and step kernels): everything the NEXT launch needs from the particles this workgroup
+// has just created -- tile maximum m_b, the tile-local inclusive scan of exp(lw - m_b) (stored per particle: the next
+// launch searches it instead of re-scanning the log-weights), its total W_b, the total E_b of the tile's exponential
+// spacings for the next resampling step (from a COPY of the lane generator: the step kernel regenerates the same words
+// from the saved state), and -- only when the next launch needs the weighted statistic sums (Nemeth lambda < 1, filter,
+// the last step) -- S_b, from the records re-read out of L2.  Two workgroup barriers on the hot path.
+// red: [NW | 2 PPT NW | H NW] doubles
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int PPT, int H, int REC, int NS, typename REAL, typename MATH>
+__device__ __forceinline__ void grid_dev_epilogue(char *base, const GridLayout &L, int np, int b, int N, const REAL (&lwn)[PPT],
+                                                  LaneRng rng, bool want_spacings, bool needS, bool store_lw, const MATH &mth,
+                                                  double *red, int tid) {
+    constexpr int NW = NT / WAVE, TILE = NT * PPT;
+    const int lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE), G = L.G;
+    double *part = reinterpret_cast<double *>(base + grid_sel(L.part, np));
+    gptr<double> csx = global_ptr(reinterpret_cast<double *>(base + grid_sel(L.cs, np)));
+    double *redP = red + NW, *redE = redP + PPT * NW, *redS = redE + PPT * NW;
+    double ml = -INFINITY;
+    bool v[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const float ef = spacing_f32(rng.next());
-        e[k] = (b * (NT * PPT) + k * NT + tid < N) ? (double)ef : 0.0;
+        v[k] = b * TILE + k * NT + tid < N;
+        const double l = v[k] ? (double)lwn[k] : -INFINITY;
+        ml = l > ml ? l : ml;
     }
-    const float extra = spacing_f32(rng.next());
-    const double Eb = tile_scan<NT, PPT>(e, c, red, wave, lane);
+    ml = wave_max(ml);
+    if (lane == 0) red[wave] = ml;
+    __syncthreads();                                                            // barrier E1
+    double mb = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mb = red[w] > mb ? red[w] : mb;
+    mb = uniform_f64(mb);
+    double p[PPT], incP[PPT];
+    float extra = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        p[k] = v[k] ? (double)mth.exp_acc((REAL)((double)lwn[k] - mb)) : 0.0;
+        incP[k] = wave_incl_scan(p[k]);
+        if (lane == WAVE - 1) redP[k * NW + wave] = incP[k];
+        if (want_spacings) {
+            // spacings are O(1) each: their in-wave running sums (< 2^10) in f32 are good to 1e-5 of a spacing; the
+            // cross-wave / cross-tile sums are f64.  The step kernel regenerates them with the same instructions.
+            const float ef = spacing_f32(rng.next());
+            const double incE = (double)wave_incl_scan_f32(v[k] ? ef : 0.0f);
+            if (lane == WAVE - 1) redE[k * NW + wave] = incE;
+        }
+    }
+    if (want_spacings) extra = spacing_f32(rng.next());         // spacing N + 1: part of the total only
+    __syncthreads();                                                            // barrier E2
+    // offsets of the (k, wave) totals in rank order, by every thread for itself (PPT NW <= 32 broadcast reads)
+    double run = 0.0, off[PPT], etot = 0.0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        off[k] = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            off[k] = w == wave ? run : off[k];
+            run += redP[k * NW + w];
+            if (want_spacings) etot += redE[k * NW + w];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = b * TILE + k * NT + tid;
+        if (v[k]) {
+            csx[i] = off[k] + incP[k];
+            if (store_lw) reinterpret_cast<REAL *>(base + grid_sel(L.lw, np))[i] = lwn[k];
+        }
+    }
     if (tid == 0) {
-        part[2 * (size_t)G + b] = Eb;
-        if (b == 0) part[7 * (size_t)G] = (double)extra;    // spacing N + 1: part of the total only
+        part[b] = mb;
+        part[G + b] = run;
+        if (want_spacings) {
+            part[2 * (size_t)G + b] = etot;
+            if (b == 0) part[7 * (size_t)G] = (double)extra;
+        }
+    }
+    if (needS) {
+        // weighted statistic sums of the tile: the records this thread has just written, re-read (rare path)
+        gptr<const REAL> recx = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.rec, np)));
+        double a[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a[h] = 0.0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = b * TILE + k * NT + tid;
+            if (v[k]) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) a[h] += (double)recx[(size_t)i * REC + NS + h] * p[k];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const double s = wave_sum(a[h]);
+            if (lane == 0) redS[h * NW + wave] = s;
+        }
+        __syncthreads();
+        if (tid < H) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += redS[tid * NW + w];
+            part[(size_t)(3 + tid) * G + b] = s;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // init: x0 (or warm start), zero statistics and log-weights, partials of step 0, generator states
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODEL, int KERNEL, typename REAL, int RNG, int NT>
+template <int MODEL, int KERNEL, typename REAL, int RNG, int NT, int PPT>
 __global__ __launch_bounds__(NT) void pfg_grid_init_kernel(const pfg_dev_problem *__restrict__ probs) {
-    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT;
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT;
     constexpr int REC = mem_rec_len<MODEL, REAL>();
     extern __shared__ __align__(16) unsigned char smem[];
     const pfg_dev_problem &P = probs[blockIdx.y];
     const int N = P.N, b = blockIdx.x, tid = threadIdx.x;
     const GridLayout L = grid_layout<MODEL, REAL>(N, RNG == PFG_RNG_REPLAY);
-    if (b >= L.G) return;
+    if (b >= L.G || L.PPT != PPT || L.NT != NT) return;
     char *base = static_cast<char *>(P.scratch);
     gptr<REAL> lw = global_ptr(reinterpret_cast<REAL *>(base + L.lw[0]));
     gptr<REAL> rec = global_ptr(reinterpret_cast<REAL *>(base + L.rec[0]));
@@ -362,19 +477,26 @@ __global__ __launch_bounds__(NT) void pfg_grid_init_kernel(const pfg_dev_problem
         }
     }
     const bool needS = is_filter || P.lambduh != 1.0 || P.T == 0;
-    grid_tile_partials<NT, H, REAL>(part, L.G, b, N, lwn, sn, needS, mth, red, tid);
-    if (RNG == PFG_RNG_DEVICE) {
-        if (P.T > 0) grid_tile_spacings<NT>(part, L.G, b, N, rng, red, tid);
+    if constexpr (RNG == PFG_RNG_DEVICE) {
+        if (b == 0) {
+            double *tabg = reinterpret_cast<double *>(base + L.tab);
+            for (int q = tid; q < TAB_E2 + 2 * TAB_LG; q += NT) tabg[q] = tabmem[q];      // the step launches load these
+            if (tid == 0) *reinterpret_cast<Consts<REAL> *>(base + L.consts) = c;         // ... and these (scalar loads)
+        }
+        __syncthreads();        // this thread's records: written above, re-read by the epilogue when needS
+        grid_dev_epilogue<NT, PPT, H, REC, NS, REAL>(base, L, 0, b, N, lwn, rng, P.T > 0, needS, true, mth, red, tid);
         reinterpret_cast<uint4 *>(base + L.rng)[b * NT + tid] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+    } else {
+        grid_tile_partials<NT, PPT, H, REAL>(part, L.G, b, N, lwn, sn, needS, mth, red, tid);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // one timestep t (0 <= t < T): resample the particles of parity t & 1, propose, weight, accumulate, write parity (t+1) & 1
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODEL, int KERNEL, typename REAL, int RNG, int NT>
+template <int MODEL, int KERNEL, typename REAL, int RNG, int NT, int PPT>
 __global__ __launch_bounds__(NT) void pfg_grid_step_kernel(const pfg_dev_problem *__restrict__ probs, int t) {
-    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT, NW = NT / WAVE;
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT, NW = NT / WAVE;
     constexpr int REC = mem_rec_len<MODEL, REAL>();
     constexpr bool DEV = RNG == PFG_RNG_DEVICE;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -382,16 +504,16 @@ __global__ __launch_bounds__(NT) void pfg_grid_step_kernel(const pfg_dev_problem
     const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL, b = blockIdx.x, tid = threadIdx.x;
     if (t >= T) return;
     const GridLayout L = grid_layout<MODEL, REAL>(N, !DEV);
-    if (b >= L.G) return;
+    if (b >= L.G || L.PPT != PPT || L.NT != NT) return;
     const int G = L.G, lane = tid & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int cp = t & 1, np = cp ^ 1;
     char *base = static_cast<char *>(P.scratch);
-    gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + L.lw[cp]));
-    gptr<REAL> lwx = global_ptr(reinterpret_cast<REAL *>(base + L.lw[np]));
-    gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + L.rec[cp]));
-    gptr<REAL> recx = global_ptr(reinterpret_cast<REAL *>(base + L.rec[np]));
-    const double *partc = reinterpret_cast<const double *>(base + L.part[cp]);
-    double *partx = reinterpret_cast<double *>(base + L.part[np]);
+    gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.lw, cp)));
+    gptr<REAL> lwx = global_ptr(reinterpret_cast<REAL *>(base + grid_sel(L.lw, np)));
+    gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.rec, cp)));
+    gptr<REAL> recx = global_ptr(reinterpret_cast<REAL *>(base + grid_sel(L.rec, np)));
+    const double *partc = reinterpret_cast<const double *>(base + grid_sel(L.part, cp));
+    double *partx = reinterpret_cast<double *>(base + grid_sel(L.part, np));
     double *head = reinterpret_cast<double *>(base + L.head);
 
     double *pw = reinterpret_cast<double *>(smem);                       // [G + 1]
@@ -488,98 +610,8 @@ __global__ __launch_bounds__(NT) void pfg_grid_step_kernel(const pfg_dev_problem
         else propagate(std::integral_constant<int, PFG_STAT_SUFF>{}, k, i, a, z);
     };
 
-    LaneRng rng = {};
-    if constexpr (DEV) {
-        // ---- sorted uniforms of this tile's children: the spacings the previous launch totalled, regenerated ----------
-        {
-            const uint4 s = reinterpret_cast<const uint4 *>(base + L.rng)[b * NT + tid];
-            rng.s0 = s.x; rng.s1 = s.y; rng.s2 = s.z; rng.s3 = s.w;
-        }
-        double e[PPT], ce[PPT], u[PPT];
-        int pt[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const float ef = spacing_f32(rng.next());
-            e[k] = (b * TILE + k * NT + tid < N) ? (double)ef : 0.0;
-        }
-        (void)rng.next();                                   // the (N+1)-th spacing's word (tile 0's went into the total)
-        tile_scan<NT, PPT>(e, ce, red, wave, lane);
-        unsigned long long *bitmap = reinterpret_cast<unsigned long long *>(tab2 + TILE);
-        for (int q = tid; q < GRID_MAX_TILES / 64; q += NT) bitmap[q] = 0ull;
-        __syncthreads();
-        int ptmin = G, ptmax = -1;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = b * TILE + k * NT + tid;
-            u[k] = (R.PE_own + ce[k]) * R.invEtot;
-            // parent tile: number of tiles whose CDF ends at or below u (pw[pt + 1] / W <= u)
-            int lo = 0, hi = G - 1;                         // answer in [0, G-1]
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (pw[mid + 1] * R.invW <= u[k]) lo = mid + 1; else hi = mid;
-            }
-            pt[k] = lo;
-            if (i < N) {
-                ptmin = lo < ptmin ? lo : ptmin;
-                ptmax = lo > ptmax ? lo : ptmax;
-                atomicOr(&bitmap[lo >> 6], 1ull << (lo & 63));
-                if (P.trace_x && P.rec_ud) P.rec_ud[(size_t)t * N + i] = u[k];
-            }
-        }
-        // children are sorted: the tile's range of parent tiles is [first valid child's, last valid child's]
-        {
-            float fmin = (float)ptmin, fmax = (float)ptmax;
-            fmin = -wave_max(-fmin); fmax = wave_max(fmax);
-            __syncthreads();
-            if (lane == 0) { red[wave] = (double)fmin; red[NW + wave] = (double)fmax; }
-            __syncthreads();
-            double a = red[0], z = red[NW];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) { a = red[w] < a ? red[w] : a; z = red[NW + w] > z ? red[NW + w] : z; }
-            ptmin = (int)a; ptmax = (int)z;
-        }
-        REAL zk[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; k += 2) mth.normal_pair(rng.next(), rng.next(), zk[k], zk[k + 1]);
-        if (P.trace_x && P.rec_z) {
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = b * TILE + k * NT + tid;
-                if (i < N) P.rec_z[(size_t)t * N + i] = (double)zk[k];
-            }
-        }
-        double *cdfl = tab2;                                // [TILE]
-        for (int ptile = ptmin; ptile <= ptmax; ++ptile) {
-            if (!((bitmap[ptile >> 6] >> (ptile & 63)) & 1ull)) continue;       // uniform: no child descends from this tile
-            // ---- rebuild the tile's CDF segment from its log-weights (the same scan its owner totalled) --------------
-            const double mb = partc[ptile];
-            const double sc = uniform_f64(::exp(mb - R.m));
-            const double pw0 = pw[ptile];
-            const int nvalid = (N - ptile * TILE) < TILE ? (N - ptile * TILE) : TILE;
-            double p[PPT], cc[PPT];
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int j = ptile * TILE + k * NT + tid;
-                p[k] = j < N ? (double)mth.exp_acc((REAL)((double)lwc[j] - mb)) : 0.0;
-            }
-            tile_scan<NT, PPT>(p, cc, red, wave, lane);
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) cdfl[k * NT + tid] = (k * NT + tid < nvalid) ? (pw0 + cc[k] * sc) * R.invW : 2.0;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = b * TILE + k * NT + tid;
-                if (i < N && pt[k] == ptile) {
-                    int pos = 0;
-#pragma unroll
-                    for (int step = TILE >> 1; step >= 1; step >>= 1) pos += (cdfl[pos + step - 1] <= u[k]) ? step : 0;
-                    pos = pos < nvalid - 1 ? pos : nvalid - 1;
-                    step_child(k, i, ptile * TILE + pos, zk[k]);
-                }
-            }
-            // (the next rebuild's tile_scan starts with a barrier: cdfl is not overwritten while it is searched)
-        }
-    } else {
+    static_assert(!DEV, "the device-generator timestep is pfg_grid_step_dev_kernel (pfg_grid_dev_kernel.hpp)");
+    {
         // ---- REPLAY: the reference's uniforms in index order against the reference's CDF (pfg_grid_cdf_kernel) --------
         const gptr<const double> cdf = global_ptr(reinterpret_cast<const double *>(base + L.cdf));
         const gptr<const double> coarse_g = global_ptr(reinterpret_cast<const double *>(base + L.coarse));
@@ -628,33 +660,29 @@ __global__ __launch_bounds__(NT) void pfg_grid_step_kernel(const pfg_dev_problem
 
     // ---- epilogue: partials of the children for the next launch -------------------------------------------------------
     const bool needS_next = needS_every || (t + 1 == T);
-    grid_tile_partials<NT, H, REAL>(partx, G, b, N, lwn, sn, needS_next, mth, red, tid);
-    if constexpr (DEV) {
-        if (t + 1 < T) grid_tile_spacings<NT>(partx, G, b, N, rng, red, tid);
-        reinterpret_cast<uint4 *>(base + L.rng)[b * NT + tid] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-    }
+    grid_tile_partials<NT, PPT, H, REAL>(partx, G, b, N, lwn, sn, needS_next, mth, red, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // finish (after the last step): W_T, the mean statistic (average_statistic, buffered_smoother.py:151-154), the last
 // log-likelihood term; final particles on request.  One workgroup per window reduces, the grid copies.
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODEL, typename REAL, int RNG, int NT>
+template <int MODEL, typename REAL, int RNG, int NT, int PPT>
 __global__ __launch_bounds__(NT) void pfg_grid_finish_kernel(const pfg_dev_problem *__restrict__ probs) {
-    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, PPT = GRID_PPT, TILE = NT * PPT, NW = NT / WAVE;
+    constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT, NW = NT / WAVE;
     constexpr int REC = mem_rec_len<MODEL, REAL>();
     extern __shared__ __align__(16) unsigned char smem[];
     const pfg_dev_problem &P = probs[blockIdx.y];
     const int N = P.N, T = P.T, b = blockIdx.x, tid = threadIdx.x;
     const GridLayout L = grid_layout<MODEL, REAL>(N, RNG == PFG_RNG_REPLAY);
-    if (b >= L.G) return;
+    if (b >= L.G || L.PPT != PPT || L.NT != NT) return;
     const int cp = T & 1;
     char *base = static_cast<char *>(P.scratch);
     const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
     if (b == 0) {
         double *pw = reinterpret_cast<double *>(smem);
         double *red = pw + (GRID_MAX_TILES + 1);
-        const double *partc = reinterpret_cast<const double *>(base + L.part[cp]);
+        const double *partc = reinterpret_cast<const double *>(base + grid_sel(L.part, cp));
         double *head = reinterpret_cast<double *>(base + L.head);
         const Math<double, false> mth = {};
         const GridReduced R = grid_reduce_partials<NT>(partc, L.G, 0, true, false, H, mth, pw, red, tid);
@@ -673,8 +701,8 @@ __global__ __launch_bounds__(NT) void pfg_grid_finish_kernel(const pfg_dev_probl
         }
     }
     if (P.final_x) {
-        gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + L.lw[cp]));
-        gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + L.rec[cp]));
+        gptr<const REAL> lwc = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.lw, cp)));
+        gptr<const REAL> recc = global_ptr(reinterpret_cast<const REAL *>(base + grid_sel(L.rec, cp)));
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = b * TILE + k * NT + tid;

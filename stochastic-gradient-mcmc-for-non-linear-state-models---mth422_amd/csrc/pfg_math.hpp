@@ -63,6 +63,20 @@ __device__ __forceinline__ double wave_incl_scan(double v) {
     return v;
 }
 __device__ __forceinline__ double wave_sum(double v) { return bcast_lane63(wave_incl_scan(v)); }
+// the same in f32: one v_add_f32 with a DPP operand per step (6 instructions; the f64 form moves two halves per step)
+template <int CTRL>
+__device__ __forceinline__ float dpp_shr0_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_incl_scan_f32(float v) {
+    v += dpp_shr0_f32<0x111>(v);
+    v += dpp_shr0_f32<0x112>(v);
+    v += dpp_shr0_f32<0x114>(v);
+    v += dpp_shr0_f32<0x118>(v);
+    v += dpp_f32<0x142, 0xa>(0.0f, v);
+    v += dpp_f32<0x143, 0xc>(0.0f, v);
+    return v;
+}
 
 // a value every lane of the wave holds identically: pin it in scalar registers (2 SGPRs instead
 // of 2 VGPRs for as long as it lives)

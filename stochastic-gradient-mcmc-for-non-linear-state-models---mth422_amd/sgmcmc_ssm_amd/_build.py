@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(CSRC, "libpfgrad.so")
 _UNITS = ["svm_prior", "garch_prior", "garch_optimal", "lgssm_prior", "lgssm_optimal"]
 SOURCES = ["pfgrad.hip", "pfg_legacy_rng.hip"] + ["pfg_inst_{0}_{1}.hip".format(u, r) for u in _UNITS for r in ("device", "replay")]
 HEADERS = [os.path.join(CSRC, h) for h in ("pfg_device.hpp", "pfg_math.hpp", "pfg_models.hpp", "pfg_reg_kernel.hpp",
-                                           "pfg_mem_kernel.hpp", "pfg_big_kernel.hpp", "pfg_grid_kernel.hpp", "pfg_grid_cdf.hpp", "pfg_elementwise.hpp", "pfg_host.hpp",
+                                           "pfg_mem_kernel.hpp", "pfg_big_kernel.hpp", "pfg_grid_kernel.hpp", "pfg_grid_dev_kernel.hpp", "pfg_grid_cdf.hpp", "pfg_elementwise.hpp", "pfg_host.hpp",
                                            "pfg_launch.hpp")] + \
           [os.path.join(INCLUDE, "pfgrad.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]

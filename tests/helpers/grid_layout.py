@@ -11,8 +11,8 @@ def _al(x):
 def grid_layout(model, dtype, N, replay):
     rs = 8 if dtype == "f64" else 4
     L = {"N": N}
-    L["NT"] = 256 if N <= (1 << 18) else 512
-    L["TILE"] = 4 * L["NT"]
+    L["TILE"] = 1024 if N <= (1 << 19) else 2048
+    L["NT"] = 256 if N <= (1 << 19) else 512           # (256 x 4 | 512 x 4: the default build)
     L["G"] = (N + L["TILE"] - 1) // L["TILE"]
     S = 64
     while (N + S - 1) // S > 16384:
@@ -30,6 +30,12 @@ def grid_layout(model, dtype, N, replay):
         L["part"].append(o); o = _al(o + (7 * L["G"] + 8) * 8)
     L["rng"] = o; o = _al(o + L["G"] * L["NT"] * 16)
     L["head"] = o; o = _al(o + 32 * 8)
+    if not replay:
+        L["cs"] = []
+        for _ in range(2):
+            L["cs"].append(o); o = _al(o + N * 8)
+        L["tab"] = o; o = _al(o + (128 + 256) * 8)
+        L["consts"] = o; o = _al(o + 23 * 8)
     if replay:
         L["cdf"] = o; o = _al(o + N * 8)
         L["coarse"] = o; o = _al(o + L["C"] * 8)

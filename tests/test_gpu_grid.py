@@ -63,8 +63,9 @@ GIANT = [
     ("svm", "prior", [0.95, 1.4, 1.4], 20000, 10, "poyiadjis_N", 1.0),
     ("garch", "optimal", [0.0, 2.0, 2.0, 1.8], 70001, 6, "nemeth", 0.9),
     ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 131072, 5, "nemeth", 0.95),
-    ("garch", "prior", [0.0, 2.0, 2.0, 1.8], 300000, 3, "poyiadjis_N", 1.0),     # 2048-particle tiles
+    ("garch", "prior", [0.0, 2.0, 2.0, 1.8], 300000, 3, "poyiadjis_N", 1.0),
     ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 262145, 3, "filter", 1.0),
+    ("svm", "prior", [0.9, 1.2, 1.1], 1000003, 3, "poyiadjis_N", 1.0),            # 2048-particle tiles (N > 2^19)
     ("svm", "prior", [0.9, 1.2, 1.1], 50000, 6, "filter", 1.0),
 ]
 
@@ -81,7 +82,7 @@ def test_giant_replay_ancestors_are_the_references(ctx, case):
     q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="replay", N=N,
              t1=t1, tL=tL, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w, theta=theta, z0=z0, u=u, z=z)
     o = ctx.run_batch([q], want_final=True, want_trace=True)[0]
-    assert ctx.last_variant() == ("grid512x4" if N > (1 << 18) else "grid256x4")
+    assert ctx.last_variant() == ("grid2048" if N > (1 << 19) else "grid1024")
     r = po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel, pf=pf, lambduh=lam, t1=t1, tL=tL, weights=w,
                      prior_mean=0.0, prior_var=1.5, save_all=True)
     flips = int(np.sum(o["all_ancestors"] != r["all_ancestors"]))
@@ -216,10 +217,10 @@ def test_cdf_kernel_is_numpy_bit_for_bit(ctx, kind, N):
 # DEVICE generator: the launch replayed by the oracle from its recorded draws
 # ---------------------------------------------------------------------------------------------------------------------
 def grid_device_ancestors(logw, u, TILE):
-    """The resampling of pfg_grid_step_kernel<.., PFG_RNG_DEVICE> (a restatement of the KERNEL's CDF layout, not of the
-    reference: both draw ancestors i.i.d. from softmax(logw)): tile-wise maxima m_b and sums W_b = sum exp(lw - m_b);
-    tile prefix PW over W_b exp(m_b - m); child u -> parent tile = #{b: PW[b+1] / W <= u} (at most G-1), position inside =
-    #{j: (PW[b] + cumsum(exp(lw - m_b))[j] exp(m_b - m)) / W <= u} (at most the tile's last particle)."""
+    """The resampling of pfg_grid_step_dev_kernel (a restatement of the KERNEL's CDF layout, not of the reference: both
+    draw ancestors i.i.d. from softmax(logw)): tile-wise maxima m_b and local scans cs_b = cumsum(exp(lw - m_b)) with totals
+    W_b; PWn = cumsum(W_b exp(m_b - m)) / W (where tile b's CDF ends), scn_b = exp(m_b - m) / W; child u -> parent tile =
+    #{b <= G-2: PWn[b] <= u}, position inside = #{j: PWn[b-1] + cs_b[j] scn_b <= u} (at most the tile's last particle)."""
     N = logw.shape[0]
     G = (N + TILE - 1) // TILE
     mb = np.array([np.max(logw[b * TILE:(b + 1) * TILE]) for b in range(G)])
@@ -227,13 +228,14 @@ def grid_device_ancestors(logw, u, TILE):
     sc = np.exp(mb - m)
     cs = [np.cumsum(np.exp(logw[b * TILE:(b + 1) * TILE] - mb[b])) for b in range(G)]
     Wb = np.array([c[-1] for c in cs])
-    PW = np.concatenate(([0.0], np.cumsum(Wb * sc)))
+    PW = np.cumsum(Wb * sc)
     invW = 1.0 / PW[-1]
-    pt = np.minimum(np.searchsorted(PW[1:] * invW, u, side="right"), G - 1)
+    PWn, scn = PW * invW, sc * invW
+    pt = np.searchsorted(PWn[:G - 1], u, side="right")
     anc = np.empty(N, dtype=np.int64)
     for b in np.unique(pt):
         sel = pt == b
-        F = (PW[b] + cs[b] * sc[b]) * invW
+        F = (PWn[b - 1] if b > 0 else 0.0) + cs[b] * scn[b]
         pos = np.minimum(np.searchsorted(F, u[sel], side="right"), F.shape[0] - 1)
         anc[sel] = b * TILE + pos
     return anc
@@ -244,6 +246,7 @@ DEVICE_CASES = [
     ("garch", "optimal", [0.0, 2.0, 2.0, 1.8], 50001, 5, "nemeth", 0.9),
     ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 100000, 4, "filter", 1.0),
     ("svm", "prior", [0.9, 1.2, 1.1], 300000, 4, "poyiadjis_N", 1.0),
+    ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 1200000, 3, "nemeth", 0.9),          # 2048-particle tiles (N > 2^19)
 ]
 
 
@@ -258,7 +261,7 @@ def test_giant_device_launch_replayed_by_oracle(ctx, case):
     q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="device", N=N,
              t1=t1, tL=tL, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w, theta=theta, seed=1234 + N, stream=7)
     o = ctx.run_batch([q], want_final=True, want_trace=True, want_draws=True)[0]
-    TILE = 2048 if N > (1 << 18) else 1024
+    TILE = 2048 if N > (1 << 19) else 1024
     ud = o["rec_ud"]
     assert np.all(np.diff(ud, axis=1) >= 0) and ud.min() > 0 and ud.max() < 1          # sorted uniforms, rank order
     flips = [0]
@@ -319,7 +322,7 @@ def test_million_particles_kalman_ground_truth_and_resampling_counts(ctx):
     for s in range(4):
         q["stream"] = s
         outs.append(ctx.run_batch([dict(q)])[0])
-    assert ctx.last_variant() == "grid512x4"
+    assert ctx.last_variant() == "grid2048"
     g = np.array([o["mean_stat"] for o in outs])
     ll = np.array([o["loglik"] for o in outs])
     # small-N runs of the one-workgroup kernels on the same data: their mean converges to the same place like 1/N
@@ -336,3 +339,46 @@ def test_million_particles_kalman_ground_truth_and_resampling_counts(ctx):
     assert np.all(np.abs(g - g.mean(axis=0)) < 6 * sd_big + 1e-12), (g, sd_big)
     assert np.all(np.abs(g.mean(axis=0) - gs.mean(axis=0)) < 6 * se + 6 * sd_big + 5e-3 * np.abs(gs.mean(axis=0)) + 1e-2), (g.mean(axis=0), gs.mean(axis=0), se)
     assert np.ptp(ll) < 0.05 and abs(ll.mean() - np.mean([o["loglik"] for o in small])) < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the REFERENCE's own giant-N calls (tests/golden/giant.npz, written by make_golden.py from the reference itself):
+# helper.pf_gradient_estimate(pf='poyiadjis_N', N=1000000) on the buffered 48-step window of
+# gradient_error_fig_scripts/svm_grad_compare.py:58-82 (garch_grad_compare.py:66-93: 40 steps), through the drop-in Helper
+# ---------------------------------------------------------------------------------------------------------------------
+def _giant_cases():
+    from conftest import Golden
+    g = Golden("giant.npz")
+    return [(g, m) for m in g.meta]
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_reference_giant_calls_seed_for_seed(idx):
+    """np.random.seed(s); helper.pf_gradient_estimate(N = 10^5 | 3 10^5 | 10^6) = the reference's numbers to rtol 1e-9
+    (the north-star bar is 1e-4 ||g||), and the NEXT np.random draw is the reference's: the call consumed exactly what
+    the reference consumes.  A parallel scan in place of NumPy's sequential cumsum flips an ancestor every ~16 steps at
+    N = 10^6 (pfg_grid_cdf.hpp) and a flipped ancestor decorrelates the run: this test is what that kernel is for."""
+    from test_gpu_paris import _helper_for, _params_for
+    from test_host_logic import vec
+    g, m = _giant_cases()[idx]
+    key = m["key"]
+    helper = _helper_for(g, m)
+    p = _params_for(m["model"], g.get(key, "theta"))
+    kw = dict(observations=g.get(key, "y").reshape(-1, 1), parameters=p, subsequence_start=m["t1"], subsequence_end=m["tL"],
+              weights=g.get(key, "weights"), pf=m["pf"], N=m["N"], kernel=m["kernel"], **m["kwargs"])
+    if m["has_grad"]:
+        np.random.seed(m["seed"])
+        grad = helper.pf_gradient_estimate(**kw)
+        nxt = np.random.random_sample()
+        ref = g.get(key, "grad")
+        got = vec(m["model"], grad)
+        l2 = np.linalg.norm(got - ref)
+        print("giant", key, m["model"], m["N"], "grad L2 err", l2, "of", np.linalg.norm(ref))
+        assert l2 <= 1e-9 * max(1.0, np.linalg.norm(ref)), (m, got, ref)
+        assert nxt == float(g.get(key, "next_draw"))
+    if m["has_loglik"]:
+        np.random.seed(m["seed"])
+        ll = helper.pf_loglikelihood_estimate(**kw)
+        nxt = np.random.random_sample()
+        assert abs(ll - float(g.get(key, "loglik"))) <= 1e-9 * abs(float(g.get(key, "loglik"))), (m, ll)
+        assert nxt == float(g.get(key, "next_draw_loglik"))

@@ -206,3 +206,39 @@ def test_paris_seed_fixtures_oracle_bit_exact():
             assert rng.random_sample() == float(g.get(key, next_name)), (m, stat)
         n += 1
     assert n == 11
+
+
+def test_giant_fixtures_oracle_bit_exact():
+    """Round 4: the reference's own giant-N calls (giant.npz: the 48-step window of svm_grad_compare.py:58-82 with
+    N = 10^5 and 10^6, garch_grad_compare.py:66-93, an LGSSM Nemeth window, a filter log-likelihood) -- the oracle
+    reproduces gradient and log-likelihood with abs-err 0.0 and leaves the generator where the reference leaves it.
+    (This pins the oracle at the sizes where the kernels' resampling CDF has to be NumPy's cumsum bit for bit.)"""
+    from conftest import Golden
+    g = Golden("giant.npz")
+    names = {"svm": ("A", "LQinv_vec", "LRinv_vec"), "lgssm": ("A", "C", "LQinv_vec", "LRinv_vec"),
+             "garch": ("log_mu", "logit_phi", "logit_lambduh", "LRinv_vec")}
+    n = 0
+    for m in g.meta:
+        key = m["key"]
+        theta, y = g.get(key, "theta"), g.get(key, "y")
+        if m["model"] == "garch":
+            pm, pv = po.garch_prior_x(theta)
+            pv = float(np.asarray(pv).reshape(-1)[0])
+        else:
+            pv = 1.0 / float(g.get(key, "fm_precision")[0])
+            pm = float(g.get(key, "fm_mean_precision")[0]) / pv
+        kernel = m["kernel"] or po.DEFAULT_KERNEL[m["model"]]
+        kw = dict(kernel=kernel, pf=m["pf"], t1=m["t1"], tL=m["tL"], weights=g.get(key, "weights"), prior_mean=pm, prior_var=pv,
+                  **m["kwargs"])
+        if m["has_grad"]:
+            rng = np.random.RandomState(m["seed"])
+            got = po.pf_gradient_estimate(m["model"], theta, y, m["N"], rng=rng, **kw)
+            assert np.array_equal(np.array([got[k] for k in names[m["model"]]]), g.get(key, "grad")), m
+            assert rng.random_sample() == float(g.get(key, "next_draw")), m
+        if m["has_loglik"]:
+            rng = np.random.RandomState(m["seed"])
+            ll = po.pf_loglikelihood_estimate(m["model"], theta, y, m["N"], rng=rng, **kw)
+            assert ll == float(g.get(key, "loglik")), m
+            assert rng.random_sample() == float(g.get(key, "next_draw_loglik")), m
+        n += 1
+    assert n == 7
