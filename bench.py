@@ -64,6 +64,10 @@ CONFIGS = {
     "c3": ("garch", 1000, 1000, 16, 4, 16384, "GARCH synthetic T=1000 N=1000, SGLD buffered PF S=16 B=4, poyiadjis_N, optimal kernel (BASELINE configs[2])"),
     "c4": ("svm", 1000, 4000, -1, -1, 512, "SVM synthetic T=1000 N=4000, SGLD full sequence, poyiadjis_N (BASELINE configs[3], saturating variant)"),
     "c5": ("svm", None, 10000, 16, 4, 2048, "EURUS hourly log returns x1000, 49 gap-split segments, SeqSVM N=10000 S=16 B=4 num_sequences=1 (BASELINE configs[4])"),
+    # not a BASELINE config: the reference's OWN giant-N call of the hot-path entry -- the ground truth of its bias experiments,
+    # ten pf_gradient_estimate(pf='poyiadjis_N', N=1000000) runs on a buffered 48-step window
+    # (gradient_error_fig_scripts/svm_grad_compare.py:58-82: T = 100, L = 16, buffer_size = 16) -- as whole-GPU windows
+    "g1": ("svm", 100, 1000000, 16, 16, 10, "SVM synthetic T=100, the 48-step buffered window (L=16, B=16) of svm_grad_compare.py:58-82, poyiadjis_N, N=1000000 particles, 10 repetitions per step (whole-GPU windows)"),
 }
 STATE_STAT = {"svm": (1, 3), "garch": (2, 4), "lgssm": (1, 4)}
 
@@ -122,6 +126,124 @@ def config_workload(name):
     p, y, prior, cfg = make_workload(model, T)
     return dict(name=name, model=model, p0=p, y=y, prior=prior, S=S, B=B, kernel=cfg["kernel"], epsilon=cfg["epsilon"],
                 N=N, chains=chains, desc=desc, window_T=(T if S == -1 else S + 2 * B), data="synthetic", T_series=T)
+
+
+def run_giant(args, rank, world, dev_index, n_distinct):
+    """--config g1: one bench "step" = the reference's ground-truth computation of one trial, ten independent
+    pf_gradient_estimate(N = 10^6) repetitions of the buffered 48-step window, as ten resident whole-GPU windows
+    (pfg_launch_device_grid: 48 + 2 launches, the particle axis of every window tiled over all CUs).  `value` = windows
+    (gradient estimates) per second.  Here the SURVEY 8(d) bytes ARE the traffic: roofline.bound = "hbm"."""
+    import torch
+    from sgmcmc_ssm_amd import distributed
+    from sgmcmc_ssm_amd.grid import ResidentWindows
+    model, T_series, N, L, Bf, reps, desc = CONFIGS[args.config]
+    p, y_all, prior, cfg = make_workload(model, T_series)
+    t0 = (T_series + L) // 2
+    y = y_all[t0 - Bf:t0 + L + Bf].reshape(-1)
+    T = y.shape[0]
+    reps = args.chains_per_gpu or reps
+    theta = np.tile(p.theta(), (reps, 1))
+    dev = torch.device("cuda", dev_index)
+    rw = ResidentWindows(model, y, theta, N, kernel=cfg["kernel"], pf="poyiadjis_N", t1=Bf, tL=Bf + L, prior_mean=0.0,
+                         prior_var=10.0, dtype=args.dtype, seed=2024, stream0=rank * reps, device=dev_index)
+    for _ in range(args.warmup):
+        rw.launch()
+    torch.cuda.synchronize(dev)
+    distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        rw.launch()
+    torch.cuda.synchronize(dev)
+    distributed.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t_start
+    g, ll = rw.results()
+    if not (np.all(np.isfinite(g)) and np.all(np.isfinite(ll))):
+        raise SystemExit("non-finite gradients after the run")
+    elapsed, _ = rank_epilogue(torch.from_numpy(g).to(dev), elapsed, device=dev)
+    # the dominant kernel's launch duration: HIP events around every timestep launch of a few more repetitions
+    kern = []
+    for _ in range(min(args.steps, 5)):
+        ev = rw.launch_timed()
+        torch.cuda.synchronize(dev)
+        kern += [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(kern))
+    if rank != 0:
+        return
+    n, h = STATE_STAT[model]
+    wsize = 8 if args.dtype == "f64" else 4
+    alg_bytes = float(reps) * N * 2 * (n + 1 + h) * wsize           # per timestep launch (SURVEY 8(d))
+    alg_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+    variant = rw.ctx.last_variant()
+    key = "{0}_{1}_{2}".format(args.config, args.dtype, variant)
+    trec = (_load_json("hbm_traffic.json") or {}).get(key)
+    traffic = trec["bytes_per_launch"] * (float(reps) / trec["chains"]) if trec else None
+    roof = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel_ms": kern_ms, "kernel": "pfg_grid_step_dev_kernel (one launch = one timestep of all {0} windows)".format(reps),
+            "whole_window_ms": elapsed / args.steps * 1e3, "launches_per_step": T + 2,
+            "frac_whole_window": float(reps) * N * T * 2 * (n + 1 + h) * wsize / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "note": "whole-GPU windows: particle state streams through HBM every timestep (scan + record read, record + scan "
+                    "write = the algorithmic 2 (n + 1 + h) w bytes per particle-step); kernel_ms = HIP events around the "
+                    "timestep launches, frac_whole_window = the same bytes over the wall time of the 50-launch sequence",
+            "stale": profile_is_stale()}
+    line = {"metric": "ground-truth gradient estimates/sec (SVM 48-step buffered window, N=1000000 particles)",
+            "value": float(reps) * world * args.steps / elapsed, "unit": "windows/s", "n_gpus": n_distinct, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": desc, "baseline_config": args.config, "windows_per_gpu": reps, "chains_per_gpu": reps, "N": N,
+                       "window_T": T, "rng": "device", "kernel_variant": variant, "rng_precision": RNG_PRECISION +
+                       "; whole-GPU windows resample with sorted uniforms (exponential spacings)",
+                       "parallelism": "independent windows, {0} rank(s) x {1} windows".format(world, reps)},
+            "particle_steps_per_s": float(reps) * world * args.steps * N * T / elapsed,
+            "us_per_pf_timestep": kern_ms * 1e3, "roofline": roof}
+    if world == 1 and not args.no_single_chain:
+        line["parity"] = giant_grad_error_vs_reference(dev_index)
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pf_oracle as po
+        Ts = 24
+        t_c = time.perf_counter()
+        po.pf_gradient_estimate(model, p.theta(), y[:Ts], N, rng=np.random.RandomState(0), kernel=cfg["kernel"], pf="poyiadjis_N",
+                                t1=8, tL=16, prior_mean=0.0, prior_var=10.0)
+        el = time.perf_counter() - t_c
+        line["cpu_baseline"] = dict(value=1.0 / (el * T / Ts), unit="windows/s", cores=1, kind="port",
+                                    sample="one pf_gradient_estimate of the NumPy oracle at N = {0} on the first {1} of the window's "
+                                           "{2} timesteps ({3:.1f} s), scaled by {2}/{1}; 1 thread; the reference itself: 38 s per "
+                                           "window in the build container".format(N, Ts, T, el))
+        line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line), flush=True)
+
+
+def giant_grad_error_vs_reference(dev_index):
+    """g1's parity leg: the reference's own N = 10^6 call (tests/golden/giant.npz:g1, written by make_golden.py from the
+    reference itself) through the drop-in Helper on the REPLAY path -- np.random.seed(s), NumPy's legacy stream, the
+    reference's CDF bit for bit (pfg_grid_cdf.hpp)."""
+    path = os.path.join(ROOT, "tests", "golden", "giant.npz")
+    if not os.path.exists(path):
+        return None
+    from sgmcmc_ssm_amd.models.svm import SVMHelper, SVMParameters
+    g = np.load(path)
+    meta = [m for m in json.loads(str(g["meta"])) if m["key"] == "g1"][0]
+    th = g["g1/theta"]
+    fm = dict(log_constant=0.0, mean_precision=g["g1/fm_mean_precision"].copy(), precision=g["g1/fm_precision"].reshape(1, 1).copy())
+    helper = SVMHelper(n=1, m=1, forward_message=fm)
+    p = SVMParameters(A=np.eye(1) * th[0], LQinv=np.eye(1) * th[1], LRinv=np.eye(1) * th[2])
+    np.random.seed(meta["seed"])
+    t_c = time.perf_counter()
+    grad = helper.pf_gradient_estimate(observations=g["g1/y"].reshape(-1, 1), parameters=p, subsequence_start=meta["t1"],
+                                       subsequence_end=meta["tL"], weights=g["g1/weights"], pf=meta["pf"], N=meta["N"])
+    el = time.perf_counter() - t_c
+    nxt = np.random.random_sample()
+    got = np.array([float(np.asarray(grad[k]).reshape(-1)[0]) for k in ("A", "LQinv_vec", "LRinv_vec")])
+    ref = g["g1/grad"]
+    return {"kernel": "REPLAY whole-GPU window (reference operation order, NumPy's cumsum bit for bit, host MT19937 streams)",
+            "grad_l2_err_vs_ref": float(np.linalg.norm(got - ref)), "grad_l2_ref_norm": float(np.linalg.norm(ref)),
+            "generator_left_where_the_reference_leaves_it": bool(nxt == float(g["g1/next_draw"])),
+            "dropin_call_seconds": el,
+            "case": "helper.pf_gradient_estimate(pf='poyiadjis_N', N=1000000), 48-step window, np.random.seed({0}): reference "
+                    "fixture tests/golden/giant.npz:g1 (the reference: 38 s per call)".format(meta["seed"]),
+            "timed_kernel_parity": "tests/test_gpu_grid.py: the device-generator launch records its draws and the CPU oracle "
+                                   "replays it (zero ancestor flips, rtol 1e-8)"}
 
 
 def grad_error_vs_reference():
@@ -450,6 +572,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     n_distinct = min(world, ndev)
 
+    if args.config.startswith("g"):
+        run_giant(args, rank, world, dev_index, n_distinct)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     w = config_workload(args.config)
     model = w["model"]
     C = args.chains_per_gpu or w["chains"]

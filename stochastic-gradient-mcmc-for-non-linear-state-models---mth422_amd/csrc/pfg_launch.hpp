@@ -168,8 +168,11 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 // ---- whole-GPU window (pfg_grid_kernel.hpp): init, then per timestep [REPLAY: the reference's CDF] + the step kernel,
 // then finish; T_max + 2 (REPLAY: 2 T_max + 2) launches on `st`, no host synchronisation in between.  Every window of the
 // batch must fall into the same tile class (pfg::grid_ppt(N)); windows shorter than t_max leave their launches at once.
+// phase: PFG_GRID_ALL = init, every timestep, finish; PFG_GRID_INIT / PFG_GRID_FINISH alone; t >= 0: timestep t alone
+// (callers that put events or graph nodes between the launches)
+constexpr int PFG_GRID_ALL = -1, PFG_GRID_INIT = -2, PFG_GRID_FINISH = -3;
 template <int MODEL, int KERNEL, typename REAL, int RNG, int NT, int PPT>
-int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase) {
     constexpr int NW = NT / pfg::WAVE;
     const pfg::GridLayout L = pfg::grid_layout<MODEL, REAL>(n_max, RNG == PFG_RNG_REPLAY);
     const dim3 grid((unsigned)L.G, (unsigned)B), blk(NT);
@@ -178,12 +181,13 @@ int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_pro
     const size_t lds_fin = (size_t)(pfg::GRID_MAX_TILES + 1) * 8 + red_bytes;
     auto k_init = pfg::pfg_grid_init_kernel<MODEL, KERNEL, REAL, RNG, NT, PPT>;
     auto k_fin = pfg::pfg_grid_finish_kernel<MODEL, REAL, RNG, NT, PPT>;
-    hipLaunchKernelGGL(k_init, grid, blk, lds_init, st, dp);
+    const int t_lo = phase >= 0 ? phase : 0, t_hi = phase >= 0 ? phase + 1 : (phase == PFG_GRID_ALL ? t_max : 0);
+    if (phase == PFG_GRID_ALL || phase == PFG_GRID_INIT) hipLaunchKernelGGL(k_init, grid, blk, lds_init, st, dp);
     if constexpr (RNG == PFG_RNG_REPLAY) {
         auto k_step = pfg::pfg_grid_step_kernel<MODEL, KERNEL, REAL, RNG, NT, PPT>;
         const size_t lds_step = pfg::grid_step_lds_bytes<NT, PPT, REAL, RNG>(L.C);
         PFG_ENSURE_LDS(ctx, k_step, lds_step);
-        for (int t = 0; t < t_max; ++t) {
+        for (int t = t_lo; t < t_hi; ++t) {
             hipLaunchKernelGGL((pfg::pfg_grid_cdf_kernel<MODEL, REAL>), dim3((unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
             hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
         }
@@ -191,23 +195,23 @@ int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_pro
         auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT>;
         const size_t lds_step = pfg::grid_dev_lds_doubles<NT, PPT>(L.G) * 8;
         PFG_ENSURE_LDS(ctx, k_step, lds_step);
-        for (int t = 0; t < t_max; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
+        for (int t = t_lo; t < t_hi; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
     }
-    hipLaunchKernelGGL(k_fin, grid, blk, lds_fin, st, dp);
+    if (phase == PFG_GRID_ALL || phase == PFG_GRID_FINISH) hipLaunchKernelGGL(k_fin, grid, blk, lds_fin, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
 }
 
 template <int MODEL, int KERNEL, int RNG>
-int launch_grid_mkr(pfg_ctx *ctx, int dtype, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
+int launch_grid_mkr(pfg_ctx *ctx, int dtype, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase) {
     if (n_max > pfg::GRID_MAX_N)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::GRID_MAX_N));
     const bool big = n_max > pfg::GRID_SMALL_N;
     if (dtype == PFG_F64)
-        return big ? launch_grid_ppt<MODEL, KERNEL, double, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st)
-                   : launch_grid_ppt<MODEL, KERNEL, double, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st);
-    return big ? launch_grid_ppt<MODEL, KERNEL, float, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st)
-               : launch_grid_ppt<MODEL, KERNEL, float, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st);
+        return big ? launch_grid_ppt<MODEL, KERNEL, double, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st, phase)
+                   : launch_grid_ppt<MODEL, KERNEL, double, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st, phase);
+    return big ? launch_grid_ppt<MODEL, KERNEL, float, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st, phase)
+               : launch_grid_ppt<MODEL, KERNEL, float, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st, phase);
 }
 
 // every kernel of one (model, proposal kernel, generator): explicitly instantiated in

@@ -22,21 +22,21 @@ extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE
 extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
 extern template int launch_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, bool);
 
-extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
-extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t);
+extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_SVM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_REPLAY>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
+extern template int launch_grid_mkr<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL, PFG_RNG_DEVICE>(pfg_ctx *, int, int, int, int, const pfg_dev_problem *, hipStream_t, int);
 
 template <int MODEL, int KERNEL>
-int launch_grid_mk(pfg_ctx *ctx, int dtype, int rng, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    if (rng == PFG_RNG_REPLAY) return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, n_max, t_max, B, dp, st);
-    return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, n_max, t_max, B, dp, st);
+int launch_grid_mk(pfg_ctx *ctx, int dtype, int rng, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase) {
+    if (rng == PFG_RNG_REPLAY) return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_REPLAY>(ctx, dtype, n_max, t_max, B, dp, st, phase);
+    return launch_grid_mkr<MODEL, KERNEL, PFG_RNG_DEVICE>(ctx, dtype, n_max, t_max, B, dp, st, phase);
 }
 
 template <int MODEL, int KERNEL>
@@ -215,7 +215,7 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
 // whole-GPU windows (N above the one-workgroup kernels' maximum, or forced): NEMETH / FILTER with the score,
 // sufficient or no statistic
 int dispatch_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int t_max, int B,
-                  const pfg_dev_problem *dp, hipStream_t st) {
+                  const pfg_dev_problem *dp, hipStream_t st, int phase = -1) {
     int rc = check_combo(ctx, model, kernel, dtype, rng);
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
@@ -224,13 +224,13 @@ int dispatch_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n
     if (B > 65535) return fail(ctx, PFG_ERR_INVALID, "at most 65535 whole-GPU windows per launch");
     ctx->last_variant = n_max > pfg::GRID_SMALL_N ? "grid2048" : "grid1024";
     ctx->last_traced = true;
-    if (model == PFG_MODEL_SVM) return launch_grid_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+    if (model == PFG_MODEL_SVM) return launch_grid_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
     if (model == PFG_MODEL_GARCH) {
-        if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
-        return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+        if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
+        return launch_grid_mk<PFG_MODEL_GARCH, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
     }
-    if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st);
-    return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st);
+    if (kernel == PFG_KERNEL_PRIOR) return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
+    return launch_grid_mk<PFG_MODEL_LGSSM, PFG_KERNEL_OPTIMAL>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
 }
 
 // ---- SGLD update for resident chains ---------------------------------------------------
@@ -567,6 +567,16 @@ int pfg_launch_device_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int r
     return dispatch_grid(ctx, model, kernel, dtype, rng, n_max, T_max, B, dev_probs, (hipStream_t)hip_stream);
 }
 
+int pfg_launch_device_grid_phase(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int phase, int B,
+                                 const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid_phase: dev_probs is NULL");
+    if (phase < PFG_GRID_PHASE_FINISH) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid_phase: phase must be a timestep >= 0, PFG_GRID_PHASE_INIT or PFG_GRID_PHASE_FINISH");
+    if (phase == -1) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid_phase: use pfg_launch_device_grid for the whole window");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch_grid(ctx, model, kernel, dtype, rng, n_max, 0, B, dev_probs, (hipStream_t)hip_stream, phase);
+}
+
 int pfg_sghmc_update_device(pfg_ctx *ctx, int model, int B, double *theta, double *momentum, const double *outs,
                             const pfg_prior_hyper *hyper, double epsilon, double alpha, double Tscale,
                             uint64_t seed, uint64_t chain_offset, uint64_t *step_ctr, void *hip_stream);
@@ -835,7 +845,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                 return fail(ctx, PFG_ERR_UNSUPPORTED, id + "N > " + std::to_string(pfg::MEM_MAX_N) + " is built for pf = 'poyiadjis_N' | 'nemeth' | 'filter'");
             if (q.elementwise) return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for N <= " + std::to_string(pfg::MEM_MAX_N));
             if ((q.N > pfg::GRID_SMALL_N) != (n_max > pfg::GRID_SMALL_N))
-                return fail(ctx, PFG_ERR_INVALID, id + "whole-GPU windows of one batch must all have N <= 524288 or all N > 524288");
+                return fail(ctx, PFG_ERR_INVALID, id + "whole-GPU windows of one batch must all have N <= 1048576 or all N > 1048576");
             t_max = q.T > t_max ? q.T : t_max;
         }
     }

@@ -80,6 +80,25 @@ class ResidentWindows(object):
             self.step_ctr += 1          # the next launch draws a fresh repetition (device-side key, no host sync)
         self.launches += 1
 
+    def launch_timed(self, stream=None):
+        """The same launches, one `pfg_launch_device_grid_phase` call per timestep with a pair of HIP events around each
+        step kernel: returns the list of (start, end) events (read them after a synchronise).  Same numbers as launch()."""
+        st = stream or torch.cuda.current_stream(self.device)
+        args = (self.model, self.kernel, self.dtype, "device", self.N)
+        self.ctx.launch_device_grid_phase(*args, self.ctx.GRID_PHASE_INIT, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+        events = []
+        for t in range(self.T):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            self.ctx.launch_device_grid_phase(*args, t, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+            b.record(st)
+            events.append((a, b))
+        self.ctx.launch_device_grid_phase(*args, self.ctx.GRID_PHASE_FINISH, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+        with torch.cuda.stream(st):
+            self.step_ctr += 1
+        self.launches += 1
+        return events
+
     def results(self):
         """(mean statistic [B, h], log-likelihood [B]) of the latest launch (synchronises)."""
         o = self.out_dev.cpu().numpy()
