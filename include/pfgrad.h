@@ -133,7 +133,8 @@ typedef struct pfg_problem {
      * once <= paris_manual_threshold children are left (or after max_accept_reject rounds) one double per child for
      * its exact draw.  Replaces the addressed pools paris_idx_u / acc_u / man_u (which must then be NULL).  The number
      * of doubles consumed is data dependent: pfg_result.paris_consumed returns it (-1: the stream was too short, run
-     * again with a longer one).  The filter's own draws of a timestep (u, z) precede them in np.random's order, so a
+     * again with a longer one -- the consumption of a window is bounded by (T + 1) (4 N + 2 N Ntilde max_accept_reject +
+     * N Ntilde) doubles, a caller that still sees -1 beyond that has a different problem).  The filter's own draws of a timestep (u, z) precede them in np.random's order, so a
      * caller that reproduces np.random.seed() runs ONE timestep per call (warm start init_x / init_logw / init_stats),
      * as sgmcmc_ssm_amd.particle_filters does.  A window of several timesteps carries the cursor from one timestep to
      * the next (PARIS_NO_ACCEPT_REJECT: child i's draw j at timestep t reads double (t N + i) Ntilde + j): given the

@@ -819,6 +819,12 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
+    // the kernel is chosen from the batch's largest N: a whole-window PaRIS stream (N <= 1024, no u / z behind it) must not
+    // ride into the large-N kernel with a bigger window of the same batch
+    for (int b = 0; b < B; ++b)
+        if (ps[b].smoother == PFG_SMOOTHER_PARIS && (ps[b].flags & PFG_FLAG_PARIS_RAW_STREAM) && n_max > 1024)
+            return fail(ctx, PFG_ERR_UNSUPPORTED, "problem " + std::to_string(b) + ": PFG_FLAG_PARIS_RAW_STREAM cannot share a batch with a window of N > 1024 (N_max = " +
+                                                  std::to_string(n_max) + "): the large-N kernel takes one launch per timestep");
     bool traced = false;
     for (int b = 0; b < B; ++b)
         traced = traced || rs[b].trace_x || rs[b].trace_ll || rs[b].rec_u || rs[b].rec_z || rs[b].rec_z0 || rs[b].rec_ud || ps[b].elementwise;
@@ -888,9 +894,12 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     // runs of packed pieces (contiguous on both sides) and the direct pieces.
     struct Copy { size_t at; const double *src; size_t n; bool packed; };
     std::vector<Copy> copies;
+    bool overflow = false;               // a piece that would not fit what the sizing pass reserved (it never copies)
     auto put = [&](const double *src, size_t n) -> const double * {
         if (!src || n == 0) return nullptr;
-        if (n >= kDirectMinDoubles && host_registered(src, n * 8)) {
+        const bool direct = n >= kDirectMinDoubles && host_registered(src, n * 8);
+        if (oi + n > n_in || (!direct && oh + n > n_host)) { overflow = true; return nullptr; }
+        if (direct) {
             copies.push_back({oi, src, n, false});
         } else {
             std::memcpy(hin + oh, src, n * 8);
@@ -1016,7 +1025,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     }
 
     // ---- stage, launch, fetch -----------------------------------------------------------
-    if (oi > n_in || oh > n_host) return fail(ctx, PFG_ERR_INVALID, "pfg_run_batch: internal sizing error");
+    if (overflow || oi > n_in || oh > n_host)
+        return fail(ctx, PFG_ERR_INVALID, "pfg_run_batch: internal sizing error (an input changed its registration state during the call?)");
     for (const Copy &cp : copies)
         PFG_HIP(ctx, hipMemcpyAsync(static_cast<double *>(ctx->in.ptr) + cp.at, cp.src, cp.n * 8, hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemcpyAsync(ctx->desc.ptr, ctx->h_desc.data(), (size_t)B * sizeof(pfg_dev_problem),

@@ -226,8 +226,10 @@ def draw_replay_streams_predictive(model, N, T, t1, tL, num_steps_ahead, random_
 
 def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weights=None,
                  prior_mean=0.0, prior_var=1.0, stat="score", dtype="f64", rng="replay",
-                 seed=None, stream=None, flags=0, random_state=None, **kwargs):
-    """Build one problem dict for _capi.Context.run_batch."""
+                 seed=None, stream=None, flags=0, random_state=None, ctx=None, **kwargs):
+    """Build one problem dict for _capi.Context.run_batch.  `ctx`: the context a PaRIS window in np.random's order runs
+    on (rng='replay', pf='paris': that window has to run HERE, while its draws are due -- see below; every other problem
+    is only described, and runs where the caller hands it to run_batch)."""
     kwargs = dict(kwargs)
     kwargs.pop("tqdm", None)
     kwargs.pop("tqdm_name", None)
@@ -268,9 +270,9 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
                      prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
                      prior_var=float(np.asarray(prior_var).reshape(-1)[0]), y=y, weights=weights, theta=theta, flags=flags)
             if int(N) <= 1024:
-                q["_result"] = _paris_raw_window(q, accept_reject, mar, mst, random_state)      # the whole window in one launch
+                q["_result"] = _paris_raw_window(q, accept_reject, mar, mst, random_state, ctx=ctx)      # the whole window in one launch
             else:
-                q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state)   # one launch per timestep
+                q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state, ctx=ctx)   # one launch per timestep
             return q
         # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
         # left and draws those exactly (its own cap is 100 log10(N/10) rounds); a fixed number of
@@ -325,7 +327,7 @@ _paris_raw_hint = {}            # (N, Ntilde, accept_reject) -> doubles per time
 _RAW_CHUNK = 1 << 16            # the raw stream is drawn in chunks with the generator state kept at every boundary
 
 
-def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None):
+def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None, ctx=None):
     """One PaRIS window (N <= 1024) consuming the legacy generator EXACTLY as the reference does, in ONE launch
     (pfgrad.h: PFG_FLAG_PARIS_RAW_STREAM): the host hands the kernel what RandomState.random_sample delivers from the
     generator's current state, the kernel takes from it -- in np.random's order -- the normals of x0 and per timestep N
@@ -335,7 +337,7 @@ def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_samp
     pair of doubles the kernel points at, with the host libm NumPy uses.  Returns what _paris_replay_window returns
     minus the all_* traces (buffered_pf_wrapper(save_all=True) re-runs the launch on the same doubles for those)."""
     import math
-    ctx = _capi.default_context()
+    ctx = ctx or _capi.default_context()
     rs = np.random if random_state is None else random_state
     N, Nt, y = q["N"], q["Ntilde"], q["y"]
     T = y.shape[0]
@@ -370,7 +372,16 @@ def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_samp
         if used >= 0:
             break
         rs.set_state(state0)
-        L *= 2                                      # the stream ran out: the same window again on a longer one
+        if used != -1:
+            raise RuntimeError("PaRIS whole-window stream: the kernel reported {0} doubles consumed".format(used))
+        # -1 = the stream ran out: the same window again on a longer one.  The consumption is bounded: per timestep N
+        # uniforms, < 2.6 N doubles of normal attempts with overwhelming probability, and at most
+        # 2 N Ntilde max_accept_reject + N Ntilde doubles of backward sampling
+        bound = int((T + 1) * (4 * N + 2 * N * Nt * max(mar, 1) + N * Nt)) + 2 * _RAW_CHUNK
+        if L > 4 * bound:
+            raise RuntimeError("PaRIS whole-window stream: {0} doubles were not enough for a window whose consumption is "
+                               "bounded by {1}".format(L, bound))
+        L *= 2
     drawn = used - (1 if has_gauss else 0)          # doubles taken from the generator
     _paris_raw_hint[key] = drawn / max(T, 1)
     c = min(drawn // _RAW_CHUNK, len(states) - 1)
@@ -392,7 +403,7 @@ def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_samp
                                               paris_manual_threshold=mst, _consumed=used))     # (+ the kernel's look-ahead)
 
 
-def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None):
+def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None, ctx=None):
     """One PaRIS window consuming the legacy generator EXACTLY as the reference does (paris_smoother +
     accept_reject_based_backward_sampling, pf.py:183-341): N normals for x0, then per timestep N uniforms
     (np.random.choice), N normals (Kernel.rv) and the data-dependent run of uniforms of the backward sampling.
@@ -400,7 +411,7 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
     u / z, hands the kernel a block of further uniforms (pfg_problem.paris_stream), and afterwards rewinds the
     generator to the end of the filter's draws and advances it by exactly what the kernel reports as consumed.
     Returns the dict run_batch would (mean_stat, loglik, x_t, log_weights, statistics, all_* traces)."""
-    ctx = _capi.default_context()
+    ctx = ctx or _capi.default_context()
     rs = np.random if random_state is None else random_state
     N, Nt, y = q["N"], q["Ntilde"], q["y"]
     T, t1, tL = y.shape[0], q["t1"], min(q["tL"], y.shape[0])
@@ -440,6 +451,8 @@ def _paris_replay_window(q, accept_reject=True, max_accept_reject=None, manual_s
             rs.set_state(after_filter)
             if used >= 0:
                 break
+            if used != -1 or M > 64 * (2 * N * Nt * max(mar, 1) + N * Nt + 64):
+                raise RuntimeError("PaRIS replay: the kernel reported {0} for a block of {1} uniforms".format(used, M))
             M *= 4                      # the block ran out: the same step again with a longer one
         if used > 0:
             rs.random_sample(used)      # the generator now stands where the reference's stands
@@ -475,11 +488,15 @@ def buffered_pf_wrapper(pf, model, kernel, observations, theta, N, ctx=None,
     Returns the reference's dict: x_t (N,n), log_weights (N,), statistics ((N,h), or (h,) for
     pf='filter'), loglikelihood_estimate, plus mean_statistic (= average_statistic(out)) and,
     with save_all=True, the all_* traces of buffered_smoother.py:128-142."""
-    q = make_problem(model, kernel, pf, observations, theta, N, **kwargs)
     ctx = ctx or _capi.default_context()
+    q = make_problem(model, kernel, pf, observations, theta, N, ctx=ctx, **kwargs)
     if "_result" in q:                  # PaRIS in np.random's order: the window ran while its draws were due
         if save_all and "all_x_t" not in q["_result"]:      # (one launch, no traces kept: the same launch again with them)
-            o = ctx.run_batch([paris_replay_again(q)], want_final=True, want_trace=True)[0]
+            q2 = paris_replay_again(q)
+            o = ctx.run_batch([q2], want_final=True, want_trace=True)[0]
+            expected = q2.get("_consumed", q2["paris_stream"].shape[0])
+            if o["paris_consumed"] != expected:       # the traces must be those of the trajectory that advanced np.random
+                raise RuntimeError("PaRIS replay consumed {0} of {1} uniforms".format(o["paris_consumed"], expected))
             return _to_reference_dict(o, q)
         return _to_reference_dict(q["_result"], q)
     o = ctx.run_batch([q], want_final=want_final or save_all, want_trace=save_all)[0]

@@ -137,7 +137,7 @@ class PFHelper(object):
         if q["smoother"] == "filter":
             raise ValueError("pf = 'filter' has no per-particle statistics to average "
                              "(the reference fails in average_statistic for it)")
-        out = _pf.run_windows([q])[0]
+        out = _pf.run_windows([q], ctx=kwargs.get("ctx", None))[0]
         return self.grad_from_statistic(out["mean_statistic"])
 
     def pf_loglikelihood_estimate(self, observations, parameters, subsequence_start=0,
@@ -147,7 +147,7 @@ class PFHelper(object):
         reference accumulates alongside are not returned by it either)."""
         q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, weights,
                             pf, N, kernel, forward_message, stat="suff", **kwargs)
-        return _pf.run_windows([q])[0]["loglikelihood_estimate"]
+        return _pf.run_windows([q], ctx=kwargs.get("ctx", None))[0]["loglikelihood_estimate"]
 
     def pf_predictive_loglikelihood_estimate(self, observations, parameters, num_steps_ahead=5,
                                              subsequence_start=0, subsequence_end=None, pf="filter",
@@ -161,7 +161,7 @@ class PFHelper(object):
         q = self.pf_problem(observations, parameters, subsequence_start, subsequence_end, None,
                             pf, N, kernel, forward_message, stat="predictive",
                             num_steps_ahead=num_steps_ahead, **kwargs)
-        out = _pf.run_windows([q])[0]
+        out = _pf.run_windows([q], ctx=kwargs.get("ctx", None))[0]
         pred = np.array(out["statistics"], dtype=float)
         pred[0] = out["loglikelihood_estimate"]
         return pred
@@ -194,12 +194,12 @@ class PFHelper(object):
             # each backward sampling consumed and left the generator where the reference leaves it); the same
             # window once more in one launch, on the same numbers, with the elementwise pass behind it
             q2 = _pf.paris_replay_again(q)
-            o = _capi.default_context().run_batch([q2], want_elementwise=True)[0]
+            o = (kwargs.get("ctx", None) or _capi.default_context()).run_batch([q2], want_elementwise=True)[0]
             expected = q2.get("_consumed", q2["paris_stream"].shape[0])
             if o["paris_consumed"] != expected:
                 raise RuntimeError("PaRIS replay consumed {0} of {1} uniforms".format(o["paris_consumed"], expected))
         else:
-            o = _capi.default_context().run_batch([q], want_elementwise=True)[0]
+            o = (kwargs.get("ctx", None) or _capi.default_context()).run_batch([q], want_elementwise=True)[0]
         _pf._recycle_streams([q])
         avg = np.reshape(o["ew_mean"], (-1, 3))
         if self.model == "garch" and squared:

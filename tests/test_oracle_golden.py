@@ -96,6 +96,52 @@ def test_multinomial_matches_numpy_choice():
     assert s1.random_sample() == s2.random_sample()
 
 
+def test_device_ancestors_are_the_references_resampler_in_slot_order():
+    """Ties `po.device_ancestors` -- the restatement of the device-generator kernels' resampling the recorded-draw tests
+    replay -- to `po.multinomial_ancestors`, the reference's np.random.choice semantics (pf.py:26-30).  The kernels keep
+    the CDF in THREAD-major slot order (slot q = tid PPT + k holds particle k NT + tid; slots past N weigh 0): on the
+    slot-permuted weights, with the uniform the kernel's word stands for, u = (word + 0.5) / 2^32, the reference's
+    cumsum / searchsorted must pick the same slot
+      * 'f64_uniform' (pf_big_kernel / whole-GPU window: an fp64 CDF against the uniform itself): always;
+      * 'f64': always;
+      * 'fixed32' (LDS-resident kernels: floor(cdf 2^32) against the raw word): except where a CDF edge falls inside the
+        upper half of the word's 2^-32 cell, (word + 0.5, word + 1) / 2^32 -- expected N^2 / 2^33 children per step, each
+        then one slot further."""
+    rs = np.random.RandomState(2024)
+    n_fixed_diff, n_fixed_total = 0, 0
+    for NT, PPT, N, spread in ((256, 4, 1000, 2.0), (256, 4, 1024, 30.0), (64, 2, 100, 1.0), (1024, 4, 4000, 5.0), (512, 2, 777, 0.0),
+                               (256, 1, 200, 80.0), (1024, 1, 1000, 3.0)):
+        NP = NT * PPT
+        q = np.arange(NP)
+        particle = (q % PPT) * NT + q // PPT
+        for rep in range(6):
+            logw = rs.randn(N) * spread
+            if rep == 5:
+                logw[:] = -1e300
+                logw[rs.randint(N)] = 0.0           # one particle carries everything
+            p = np.exp(logw - np.max(logw))
+            w_slots = np.where(particle < N, p[np.minimum(particle, N - 1)], 0.0)
+            words = rs.randint(0, 2 ** 32, size=N, dtype=np.uint64).astype(np.uint32)
+            u = (words.astype(np.float64) + 0.5) / 4294967296.0
+            pos_ref = po.multinomial_ancestors(w_slots / np.sum(w_slots), u)                 # the reference, on the slots
+            anc_ref = np.minimum((np.minimum(pos_ref, NP - 1) % PPT) * NT + np.minimum(pos_ref, NP - 1) // PPT, N - 1)
+            assert np.array_equal(po.device_ancestors(logw, u, NT, PPT, cdf="f64_uniform"), anc_ref), (NT, PPT, N, rep)
+            assert np.array_equal(po.device_ancestors(logw, words, NT, PPT, cdf="f64"), anc_ref), (NT, PPT, N, rep)
+            a32 = po.device_ancestors(logw, words, NT, PPT, cdf="fixed32")
+            diff = np.flatnonzero(a32 != anc_ref)
+            n_fixed_diff += diff.size
+            n_fixed_total += N
+            # a child that differs took the next slot with positive weight
+            slot_of = np.empty(N, dtype=np.int64)
+            slot_of[particle[particle < N]] = q[particle < N]
+            for i in diff:
+                assert slot_of[a32[i]] > slot_of[anc_ref[i]], (NT, PPT, N, rep, i)
+                between = w_slots[slot_of[anc_ref[i]] + 1:slot_of[a32[i]]]
+                assert np.all(between == 0.0)
+    # expectation over these cases: sum N^2 / 2^33 ~ 2e-3
+    assert n_fixed_diff <= 2, (n_fixed_diff, n_fixed_total)
+
+
 def test_paris_oracle_bit_exact():
     """PaRIS smoother restatement vs the reference's traces (default settings and forced
     manual-sampling fallback), consuming the legacy stream in the reference's order."""
