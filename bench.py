@@ -421,28 +421,37 @@ def lds_roofline(key, chains, kern_ms, clock_ghz):
                 lds_array_cycles_per_launch=active, counters_from="profiles/lds_activity.json:" + key)
 
 
-def replay_arithmetic_leg(w, dev_index, C=768, reps=3):
-    """Throughput of the REPLAY-arithmetic kernel (reference operation order, fp64 CDF, -ffp-contract=off)
-    on device-resident pre-generated streams: the cost of parity-pinned arithmetic, on record."""
+def replay_arithmetic_leg(w, dev_index, C=None, reps=3):
+    """Throughput of the REPLAY-arithmetic kernel (reference operation order, fp64 CDF in the reference's index order,
+    -ffp-contract=off) on device-resident pre-generated streams: the cost of parity-pinned arithmetic, on record -- for
+    every config: full sequences (c1, c2, c4) and buffered windows (c3, c5: the windows of the ensemble's first step).
+    N <= 1024 runs the LDS-resident REPLAY instantiation, larger N pf_mem_kernel ("mem1024")."""
     import torch
     from sgmcmc_ssm_amd.ensemble import ChainEnsemble
-    if w["S"] != -1 or isinstance(w["y"], list):
-        return None
-    ens = ChainEnsemble(w["model"], w["y"], w["p0"], num_chains=C, N=w["N"], pf="poyiadjis_N", kernel=w["kernel"],
-                        epsilon=w["epsilon"], prior=w["prior"], subsequence_length=-1, buffer_length=-1, seed=5,
+    N = w["N"]
+    Tw = w["window_T"]
+    if C is None:
+        # as many windows as 24 GB of fp64 streams hold (2 x 8 B per particle-step), at most 768 (c2's historical figure)
+        C = int(max(32, min(768, (24 << 30) // (16 * Tw * N))))
+    ens = ChainEnsemble(w["model"], w["y"], w["p0"], num_chains=C, N=N, pf="poyiadjis_N", kernel=w["kernel"],
+                        epsilon=w["epsilon"], prior=w["prior"], subsequence_length=w["S"], buffer_length=w["B"], seed=5,
                         chain_offset=2 * 10 ** 6, device=dev_index)
-    T, N = ens.T, ens.N
     dev = ens.device
+    d = ens._desc
+    Tmax = int(d["T"].max())
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
     z0 = torch.randn((C, N), dtype=torch.float64, device=dev, generator=gen)
-    u = torch.rand((C, T, N), dtype=torch.float64, device=dev, generator=gen)
-    z = torch.randn((C, T, N), dtype=torch.float64, device=dev, generator=gen)
-    d = ens._desc
+    u = torch.rand((C, Tmax, N), dtype=torch.float64, device=dev, generator=gen)
+    z = torch.randn((C, Tmax, N), dtype=torch.float64, device=dev, generator=gen)
     idx = np.arange(C, dtype=np.uint64)
     d["z0"] = z0.data_ptr() + idx * np.uint64(8 * N)
-    d["u"] = u.data_ptr() + idx * np.uint64(8 * T * N)
-    d["z"] = z.data_ptr() + idx * np.uint64(8 * T * N)
+    d["u"] = u.data_ptr() + idx * np.uint64(8 * Tmax * N)
+    d["z"] = z.data_ptr() + idx * np.uint64(8 * Tmax * N)
+    sb = ens.ctx.scratch_bytes(ens.model, ens.dtype, "replay", N)     # the REPLAY kernel of this N may keep its state in HBM
+    if sb > 0:                                                         # where the ensemble's device-generator kernel does not
+        scratch = torch.empty(C * sb, dtype=torch.uint8, device=dev)
+        d["scratch"] = scratch.data_ptr() + idx * np.uint64(sb)
     ens.desc_dev.copy_(torch.from_numpy(d.view(np.uint8).reshape(C, -1)))
     st = torch.cuda.current_stream(dev)
 
@@ -461,10 +470,20 @@ def replay_arithmetic_leg(w, dev_index, C=768, reps=3):
     if not np.all(np.isfinite(g)):
         raise SystemExit("non-finite gradients in the replay-arithmetic leg")
     k = float(np.median(ms))
-    return dict(value=C / (k * 1e-3), unit="SGLD steps/s (PF launch only)", chains=C, kernel_ms=k,
-                kernel_variant=ens.ctx.last_variant(),
-                note="REPLAY instantiation on device-resident pre-generated fp64 streams (torch generator; the host "
-                     "MT19937 stream of the drop-in path is excluded): the arithmetic the reference fixtures pin")
+    n, h = STATE_STAT[w["model"]]
+    psteps = float(d["T"].astype(np.float64).sum()) * N
+    variant = ens.ctx.last_variant()
+    out = dict(value=C / (k * 1e-3), unit="SGLD steps/s (PF launch only)", chains=C, kernel_ms=k, kernel_variant=variant,
+               particle_steps_per_s=psteps / (k * 1e-3),
+               note="REPLAY instantiation on device-resident pre-generated fp64 streams (torch generator; the host "
+                    "MT19937 stream of the drop-in path is excluded): the arithmetic the reference fixtures pin")
+    if variant.startswith("mem"):
+        # state and streams go through memory: 2 (n + 1 + h) 8 B of state + 16 B of replayed draws per particle-step
+        alg = psteps * (2 * (n + 1 + h) * 8 + 16)
+        out["hbm_model"] = dict(algorithmic_bytes_per_launch=alg, algorithmic_GBps=alg / (k * 1e-3) / 1e9,
+                                frac_of_peak=alg / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                note="2 (n + 1 + h) 8 B of particle state + 16 B of replayed u / z per particle-step")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -716,8 +735,9 @@ def main():
         }
         if world != n_distinct:
             line["rehearsal"] = "{0} ranks folded onto {1} GPU(s): NOT a multi-GPU measurement".format(world, n_distinct)
-        if world == 1 and not args.no_single_chain and args.config == "c2":
-            line["parity"] = grad_error_vs_reference()
+        if world == 1 and not args.no_single_chain:
+            if args.config == "c2":
+                line["parity"] = grad_error_vs_reference()
             line["replay_arithmetic"] = replay_arithmetic_leg(w, dev_index)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, budget_s=args.cpu_budget)

@@ -88,6 +88,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // variant ids below zero: kernels other than the LDS-resident table entries
 constexpr int kVariantMem = -2;     // large-N kernel (state in an HBM scratch)
 constexpr int kVariantParis = -3, kVariantSystematic = -4, kVariantN2 = -5, kVariantBig = -6;
+constexpr int kVariantMemLw4 = -8;  // large-N kernel, N <= 4096, no predictive statistic: log-weights in registers
 constexpr int kVariantGrid = -7;    // whole-GPU window for N above the one-workgroup kernels' maximum (pfg_grid_kernel.hpp)
 
 // Launch of every kernel of one (model, proposal kernel, generator): defined (and explicitly

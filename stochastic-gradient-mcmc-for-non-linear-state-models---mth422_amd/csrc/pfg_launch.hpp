@@ -154,12 +154,20 @@ int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp,
     return PFG_OK;
 }
 
+// lw4: every window of the batch has N <= 4096 and none asks for the predictive statistic (the dispatcher knows): the
+// variant that keeps the log-weights in registers
 template <int MODEL, int KERNEL, typename REAL, int RNG>
-int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
+int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool lw4 = false) {
     size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    PFG_ENSURE_LDS(ctx, kern, lds);
-    hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    if (lw4 && n_max <= 4096) {
+        auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, false, true>;
+        PFG_ENSURE_LDS(ctx, kern, lds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    } else {
+        auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG>;
+        PFG_ENSURE_LDS(ctx, kern, lds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+    }
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
 }
@@ -244,9 +252,9 @@ int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_p
         if (dtype == PFG_F64) return launch_paris<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
         return launch_paris<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
     }
-    if (v == kVariantMem) {
-        if (dtype == PFG_F64) return launch_mem<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st);
-        return launch_mem<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st);
+    if (v == kVariantMem || v == kVariantMemLw4) {
+        if (dtype == PFG_F64) return launch_mem<MODEL, KERNEL, double, RNG>(ctx, n_max, B, dp, st, v == kVariantMemLw4);
+        return launch_mem<MODEL, KERNEL, float, RNG>(ctx, n_max, B, dp, st, v == kVariantMemLw4);
     }
     if (dtype == PFG_F64) return launch_v<MODEL, KERNEL, double, RNG>(ctx, v, n_max, B, dp, st, traced);
     return launch_v<MODEL, KERNEL, float, RNG>(ctx, v, n_max, B, dp, st, traced);

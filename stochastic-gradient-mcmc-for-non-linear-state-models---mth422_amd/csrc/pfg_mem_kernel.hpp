@@ -73,8 +73,15 @@ __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
            (size_t)(PFG_MAX_PRED * MEM_NW + MEM_NW + 2 * PFG_MAX_PRED) * 8 + tab_bytes<REAL, RNG, true>();
 }
 
-template <int MODEL, int KERNEL, typename REAL, int RNG, bool PARIS = false>
+#ifndef PFG_MEM_PREFETCH
+#define PFG_MEM_PREFETCH 0      /* measured (round 4, c4 REPLAY, ms per 64 / 256 chains): 22.6 / 29.1 with, 14.1 / 20.0 without: 18 more spilled VGPRs */
+#endif
+// LW4 (round 4; N <= 4096, plain statistics, not PaRIS): a thread's (<= 4) log-weights never leave its registers -- it is
+// their only reader and writer --, which takes the global-memory round trip out of the maximum and the weight phases
+// of every timestep (BASELINE config 4 through the seed-compatible path).
+template <int MODEL, int KERNEL, typename REAL, int RNG, bool PARIS = false, bool LW4 = false>
 __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *__restrict__ probs) {
+    static_assert(!(PARIS && LW4), "LW4 is a variant of the plain kernel");
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NT = MEM_NT, NW = MEM_NW;
@@ -149,13 +156,18 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     if (RNG == PFG_RNG_DEVICE)
         rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
 
+    REAL lwr[4];                                                    // LW4: this thread's log-weights (slots past N: -inf)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lwr[q] = (REAL)(-INFINITY);
     // ---- x0 or warm start ---------------------------------------------------------------
     {
         double pv = P.prior_var;
         if (MODEL == PFG_MODEL_GARCH && (P.flags & PFG_FLAG_GARCH_STATIONARY_PRIOR))
             pv = (double)c.alpha / (1.0 - (double)c.beta - (double)c.gamma);
         const double sd = sqrt(pv);
-        for (int i = tid; i < N; i += NT) {
+        for (int jj = 0; jj < MEM_MAX_CHUNKS; ++jj) {
+            const int i = jj * NT + tid;
+            if (i >= N) break;
             REAL x[NS], s[H], l0 = (REAL)0;
 #pragma unroll
             for (int d = 0; d < NS; ++d) x[d] = (REAL)0;
@@ -175,7 +187,12 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 else { REAL a, b; mth.normal_pair(rng.next(), rng.next(), a, b); z = (double)a; }
                 x[0] = (REAL)(P.prior_mean + sd * z);
             }
-            lwg[i] = l0;
+            if (LW4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lwr[q] = q == jj ? l0 : lwr[q];
+            } else {
+                lwg[i] = l0;
+            }
             alignas(16) REAL rec[REC] = {};
 #pragma unroll
             for (int d = 0; d < NS; ++d) rec[d] = x[d];
@@ -204,9 +221,27 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     double m = 0.0, W = (double)N;
 
     for (int t = 0; t <= T; ++t) {
+        // LW4 + REPLAY: this timestep's draws are asked for before anything else (they depend on nothing): their latency
+        // runs under the maximum / weight / CDF phases instead of in front of the ancestor search
+        double upre[4];
+        REAL zpre[4];
+        if (LW4 && RNG == PFG_RNG_REPLAY && PFG_MEM_PREFETCH && t < T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = g * NT + tid;
+                const int ii = i < N ? i : N - 1;
+                upre[g] = uv[(size_t)t * N + ii];
+                zpre[g] = (REAL)zv[(size_t)t * N + ii];
+            }
+        }
         // ---- (A) max of the log weights (f32-rounded shift, see wave_max) -------------------
         float ml = -INFINITY;
-        for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
+        if (LW4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ml = fmaxf(ml, (float)lwr[q]);
+        } else {
+            for (int i = tid; i < N; i += NT) ml = fmaxf(ml, (float)lwg[i]);
+        }
         ml = wave_max(ml);
         if (lane == 0) red_maxf[wave] = ml;
         const bool pred_upd = predictive && t > 0;      // fold step t-1's statistic (uniform)
@@ -241,11 +276,14 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             double part[H];
 #pragma unroll
             for (int h = 0; h < H; ++h) part[h] = 0.0;
-            for (int j = 0; j < nchunk; ++j) {
+#pragma unroll (LW4 ? 4 : 1)
+            for (int j = 0; j < (LW4 ? 4 : nchunk); ++j) {
+                if (LW4 && j >= nchunk) break;
                 const int i = j * NT + tid;
                 const bool v = i < N;
                 const int ii = v ? i : N - 1;
-                double p = (double)mth.exp((REAL)(lwg[ii] - (REAL)m));
+                const REAL lwv = LW4 ? lwr[LW4 ? j : 0] : lwg[ii];
+                double p = (double)mth.exp((REAL)(lwv - (REAL)m));
                 p = v ? p : 0.0;
                 if (needS) {
 #pragma unroll
@@ -432,6 +470,84 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                         if (P.trace_stats && !is_filter) {
 #pragma unroll
                             for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)sp[h];
+                        }
+                    }
+                }
+            }
+        };
+        // The same sweep for the plain statistics, four chunks at a time (round 4): the four children's draws are loaded
+        // together, their ancestor searches run as four independent probe chains, the four parent records are in flight
+        // together -- one exposed memory latency per group of four instead of two per child (config 4 through the
+        // seed-compatible path: 16.8 -> see DESIGN 4.2 us per timestep).  Arithmetic and its order are those of `sweep`.
+        auto sweep4 = [&](auto stat_tag) {
+            constexpr int STAT = decltype(stat_tag)::value;
+            constexpr int GQ = 4;
+            for (int j0 = 0; j0 < nchunk; j0 += GQ) {
+                int i[GQ], a[GQ], pos[GQ];
+                bool v[GQ];
+                double u[GQ];
+                REAL z[GQ];
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    i[g] = (j0 + g) * NT + tid;
+                    v[g] = i[g] < N;
+                    const int ii = v[g] ? i[g] : N - 1;
+                    if (LW4 && RNG == PFG_RNG_REPLAY && PFG_MEM_PREFETCH) { u[g] = upre[g]; z[g] = zpre[g]; }
+                    else if (RNG == PFG_RNG_REPLAY) { u[g] = uv[(size_t)t * N + ii]; z[g] = (REAL)zv[(size_t)t * N + ii]; }
+                    else { REAL zb; u[g] = u01_32(rng.next()); mth.normal_pair(rng.next(), rng.next(), z[g], zb); }
+                    pos[g] = 0;
+                }
+                for (int step = np2 >> 1; step >= 1; step >>= 1) {
+                    const int probe = step - 1 + (step >= 32 ? (step >> 5) - 1 : 0);
+                    const int adv = step + (step >> 5);
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) pos[g] += (cdf[pos[g] + probe] <= u[g]) ? adv : 0;
+                }
+                alignas(16) REAL rec[GQ][REC];
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    a[g] = np2 > 8192 ? pos[g] - pos[g] / 33 : pos[g] - ((pos[g] * 993) >> 15);
+                    a[g] = a[g] < N - 1 ? a[g] : N - 1;
+                    rec_load<REC, REAL>(rec[g], cur + (size_t)a[g] * REC);
+                    if (RNG == PFG_RNG_REPLAY && v[g]) {
+                        const double hi = cdf[cdf_phys(a[g])] - u[g];
+                        const double lo = a[g] > 0 ? u[g] - cdf[cdf_phys(a[g] - 1)] : 1.0;
+                        const double mg = hi < lo ? hi : lo;
+                        tie = mg < tie ? mg : tie;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    REAL xp[NS], sp[H], xn[NS], add[H], lwn;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) xp[d] = rec[g][d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) sp[h] = rec[g][NS + h];
+                    particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, z[g], xn, lwn, add);
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const REAL av = use_stat ? add[h] * (REAL)wt : (REAL)0;
+                        const REAL sm = (lam * sp[h] + oml * (REAL)S[h]) + av;      // pf.py:175-179 / :78-80
+                        sp[h] = is_filter ? av : sm;
+                    }
+                    if (LW4) lwr[g] = v[g] ? lwn : (REAL)(-INFINITY);       // (LW4: nchunk <= 4, one group: chunk index = g)
+                    if (v[g]) {
+                        if (!LW4) lwg[i[g]] = lwn;
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) rec[g][d] = xn[d];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) rec[g][NS + h] = sp[h];
+                        rec_store<REC, REAL>(nxt + (size_t)i[g] * REC, rec[g]);
+                        if (P.trace_x) {
+                            const size_t row = (size_t)(t + 1) * N + i[g];
+                            if (P.trace_anc) P.trace_anc[(size_t)t * N + i[g]] = a[g];
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)xn[d];
+                            P.trace_logw[row] = (double)lwn;
+                            if (P.trace_stats && !is_filter) {
+#pragma unroll
+                                for (int h = 0; h < H; ++h) P.trace_stats[row * H + h] = (double)sp[h];
+                            }
                         }
                     }
                 }
@@ -887,8 +1003,13 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
             } else if (stat == PFG_STAT_SCORE) paris_sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
             else paris_sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
         } else {
-            if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
-            else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+            // measured (round 4, profiles/r04_ab_mem_kernel.txt): the grouped sweep pays for N <= 4096 (one group); at N = 10000
+            // (ten chunks: 4 + 4 + 2) it costs 3-8 %, so the general kernel keeps the one-chunk sweep
+            if (!LW4) {
+                if (stat == PFG_STAT_SCORE) sweep(std::integral_constant<int, PFG_STAT_SCORE>{});
+                else sweep(std::integral_constant<int, PFG_STAT_SUFF>{});
+            } else if (stat == PFG_STAT_SCORE) sweep4(std::integral_constant<int, PFG_STAT_SCORE>{});
+            else sweep4(std::integral_constant<int, PFG_STAT_SUFF>{});
         }
         { REAL *tmp = cur; cur = nxt; nxt = tmp; }
         wt_prev = wt;
@@ -925,7 +1046,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         for (int i = tid; i < N; i += NT) {
 #pragma unroll
             for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)i * REC + d];
-            if (P.final_logw) P.final_logw[i] = (double)lwg[i];
+            if (P.final_logw) P.final_logw[i] = (double)(LW4 ? lwr[(i / NT) & 3] : lwg[i]);
             if (P.final_stats && !is_filter) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)i * REC + NS + h];

@@ -196,8 +196,11 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
         const char *force = std::getenv("PFGRAD_VARIANT");
         if (!(force && !std::strcmp(force, "mem1024"))) v = kVariantBig;
     }
+    // the large-N kernel with the log-weights in registers: N <= 4096, and the host knows that no window asks for the
+    // predictive statistic (pfg_run_batch routes those with force_mem; resident descriptors never carry it)
+    if (v == kVariantMem && !force_mem && n_max <= 4096) v = kVariantMemLw4;
     ctx->last_variant = v >= 0 ? kVariants[v].tag
-                        : v == kVariantMem ? "mem1024"
+                        : (v == kVariantMem || v == kVariantMemLw4) ? "mem1024"
                         : v == kVariantBig ? (n_max <= 4096 ? "big4096" : "big16384")
                         : v == kVariantParis ? (n_max <= 256 ? "paris256x1" : n_max <= 1024 ? "paris256x4" : "paris_mem1024")
                         : v == kVariantSystematic ? "systematic256x4"

@@ -93,6 +93,34 @@ if which == "dropin":
             s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
         dt = (time.perf_counter() - t0) / n
         print(f"drop-in SVMSampler.sample_sgld N=1000 {name:28s}: {dt*1e3:8.3f} ms/step  {1/dt:8.1f} steps/s", flush=True)
+if which == "dropin_large":
+    # BASELINE configs 4 and 5 through the drop-in Sampler API, seed-compatible (rng='replay': pf_mem_kernel) and device rng
+    from sgmcmc_ssm_amd.models.svm import SVMSampler, SeqSVMSampler
+    import bench
+    np.random.seed(1)
+    p, gen = params("svm")
+    y = gen(T=1000, parameters=p)["observations"]
+    for rng in ("replay", "device"):
+        s = SVMSampler(n=1, m=1, observations=y, parameters=p.copy())
+        kw = dict(kind="pf", pf="poyiadjis_N", N=4000, subsequence_length=-1, buffer_length=-1, rng=rng)
+        s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
+        dt = (time.perf_counter() - t0) / n
+        print(f"drop-in SVMSampler.sample_sgld N=4000 full T=1000 rng={rng:7s}: {dt*1e3:8.3f} ms/step  {1/dt:8.1f} steps/s", flush=True)
+    w = bench.config_workload("c5")
+    for rng in ("replay", "device"):
+        s = SeqSVMSampler(n=1, m=1, observations=w["y"], parameters=w["p0"].copy())
+        kw = dict(kind="pf", pf="poyiadjis_N", N=10000, subsequence_length=16, buffer_length=4, num_sequences=1, rng=rng)
+        s.sample_sgld(epsilon=0.001, **kw); s.project_parameters()
+        n = 100
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.sample_sgld(epsilon=0.001, **kw); s.project_parameters()
+        dt = (time.perf_counter() - t0) / n
+        print(f"drop-in SeqSVMSampler.sample_sgld EURUS N=10000 S=16 B=4 rng={rng:7s}: {dt*1e3:8.3f} ms/step  {1/dt:8.1f} steps/s", flush=True)
 if which == "paris":
     from sgmcmc_ssm_amd import _capi
     from sgmcmc_ssm_amd.particle_filters import make_problem
