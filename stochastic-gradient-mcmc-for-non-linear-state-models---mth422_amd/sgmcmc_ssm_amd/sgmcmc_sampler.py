@@ -623,6 +623,74 @@ class SGMCMCSampler(object):
             raise ValueError("Unrecognized iter_type {0}".format(iter_type))
         return names * steps_per_iteration, kws * steps_per_iteration
 
+    # -- resident fit: rng='device' SGLD runs on the GPU without the host in the loop ----------------------------
+    _RESIDENT_PF_KEYS = frozenset(("pf", "N", "kernel", "lambduh", "rng", "dtype", "resampling", "tqdm", "resident"))
+
+    def _resident_plan(self, iter_type, kwargs):
+        """fit / fit_timed / fit_evaluate with iter_type='SGLD' and pf_kwargs=dict(rng='device', ...): the step
+        (sample_sgld + project_parameters, sgmcmc_sampler.py:549-567, 650-656 of the reference) needs nothing from the
+        host -- window start, particle filter, Langevin noise and projection are all device kernels of ChainEnsemble
+        -- so the loop runs RESIDENT: a one-chain ensemble, K steps per hipGraph replay, parameters copied back at the
+        reference's save points.  Returns the ensemble's arguments, or None when the step has to stay on the host
+        (rng='replay': np.random's order is the contract there; other iter types; minibatches; options the device
+        update does not know).  pf_kwargs['resident'] = False keeps the host loop."""
+        pfkw = dict(kwargs.get("pf_kwargs", {}))
+        if iter_type != "SGLD" or pfkw.get("rng", "replay") not in ("device", "philox") or pfkw.get("resident", True) is False:
+            return None
+        if kwargs.get("kind", "pf") != "pf" or kwargs.get("minibatch_size", 1) != 1:
+            return None
+        if getattr(self, "options", None) or kwargs.get("project_kwargs"):
+            return None
+        if set(pfkw) - self._RESIDENT_PF_KEYS or pfkw.get("pf", "poyiadjis_N") not in ("poyiadjis_N", "nemeth"):
+            return None
+        obs = self.observations
+        is_list = isinstance(obs, (list, tuple))
+        if is_list != isinstance(self, SeqSGMCMCSampler) or obs is None:
+            return None
+        if is_list and kwargs.get("num_sequences", -1) != 1:
+            return None             # the ensemble's sequence lists draw ONE sequence per step (num_sequences = 1)
+        if int(pfkw.get("N", 1000)) > 16384:
+            return None
+        return dict(N=int(pfkw.get("N", 1000)), pf=pfkw.get("pf", "poyiadjis_N"), lambduh=pfkw.get("lambduh", None),
+                    kernel=pfkw.get("kernel", None), dtype=pfkw.get("dtype", "f64"),
+                    resampling=pfkw.get("resampling", "multinomial"), epsilon=float(kwargs["epsilon"]),
+                    S=int(kwargs["subsequence_length"]), B=int(kwargs["buffer_length"]),
+                    spi=int(kwargs.get("steps_per_iteration", 1)), is_list=is_list)
+
+    def _resident_ensemble(self, plan):
+        """The one-chain ensemble of a resident fit.  Its device generator is keyed from np.random (two randint draws), so
+        np.random.seed(s) before fit reproduces the run; (seed, chain 0) is what a ChainEnsemble built by hand with the
+        same arguments runs -- bit for bit (tests/test_gpu_sampler.py)."""
+        from .ensemble import ChainEnsemble
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) | (int(np.random.randint(0, 2 ** 31 - 1)) << 31)
+        return ChainEnsemble(self.message_helper.model, self.observations, self.parameters, num_chains=1, N=plan["N"],
+                             pf=plan["pf"], lambduh=plan["lambduh"], kernel=plan["kernel"], epsilon=plan["epsilon"],
+                             prior=self.prior, subsequence_length=plan["S"], buffer_length=plan["B"], dtype=plan["dtype"],
+                             seed=seed, chain_offset=0, forward_message=getattr(self, "forward_message", None),
+                             resampling=plan["resampling"], window_sampling="host" if plan["is_list"] else "device")
+
+    @staticmethod
+    def _graph_steps(ens, thin):
+        """Largest K <= 64 dividing `thin` (steps between two saved states) when the ensemble's step can be captured."""
+        if ens.S != -1 and ens.window_sampling != "device":
+            return 0
+        for K in range(min(64, thin), 0, -1):
+            if thin % K == 0:
+                return K
+        return 0
+
+    def _fit_resident(self, plan, num_iters, output_all):
+        ens = self._resident_ensemble(plan)
+        steps = num_iters * plan["spi"]
+        history = [self.parameters.copy()] if output_all else None
+        if steps > 0:
+            thin = plan["spi"] if output_all else steps
+            samples = ens.run(steps, thin=thin, graph_steps=self._graph_steps(ens, thin))
+            if output_all:
+                history += [ens._params_from_theta(th[0]) for th in samples]
+            self.parameters = ens._params_from_theta(samples[-1][0])
+        return history if output_all else self.parameters.copy()
+
     def _run_iter(self, names, kws):
         for name, kw in zip(names, kws):
             getattr(self, name)(**kw)
@@ -636,6 +704,9 @@ class SGMCMCSampler(object):
         if init_parameters is not None:
             self.parameters = init_parameters.copy()
         names, kws = self.get_iter_step(iter_type, **kwargs)
+        plan = self._resident_plan(iter_type, kwargs)
+        if plan is not None:
+            return self._fit_resident(plan, num_iters, output_all)
         history = [self.parameters.copy()] if output_all else None
         steps = range(1, num_iters + 1)
         if tqdm is not None:
@@ -687,12 +758,46 @@ class SGMCMCSampler(object):
         saved, times, iterations = [self.parameters.copy()], [0.0], [0]
         evaluate(0)
         iteration, total_time = 0, 0.0
+        plan = self._resident_plan(iter_type, kwargs)
+        ens = self._resident_ensemble(plan) if plan is not None else None
+        burst = 0
+        if ens is not None:
+            # resident: `burst` iterations per call (one hipGraph replay of K steps each when the step can be captured),
+            # the clock is read after every burst; metrics see the parameters of the save point, as in the host loop
+            K = self._graph_steps(ens, 64 * plan["spi"])
+            burst = max(1, (K or plan["spi"]) // plan["spi"])
+
+            def run_burst():
+                th = ens.run(burst * plan["spi"], thin=burst * plan["spi"], graph_steps=K)
+                self.parameters = ens._params_from_theta(th[-1][0])
         start, last_save = time.time(), time.time()
         saves = range(1, num_saves + 1)
         if tqdm is not None:
             saves = tqdm(saves)
         try:
             for _ in saves:
+                if ens is not None:
+                    # (the reference caps a save interval at 1000 iterations, sgmcmc_sampler.py:845-867 -- with its
+                    # 20 ms steps never reached; at 70 us per resident step the cap would end a 60-s fit after 4 s, so
+                    # the resident loop keeps to the interval's meaning: step until min_save_time has passed, save)
+                    done = 0
+                    while True:
+                        run_burst()
+                        done += burst
+                        if time.time() - last_save > min_save_time:
+                            total_time += time.time() - last_save
+                            iteration += done
+                            saved.append(self.parameters.copy())
+                            times.append(total_time)
+                            iterations.append(iteration)
+                            evaluate(iteration)
+                            last_save = time.time()
+                            break
+                    if total_time > max_time:
+                        break
+                    if total_max_time is not None and time.time() - start > total_max_time:
+                        break
+                    continue
                 for step in range(1000):
                     self._run_iter(names, kws)
                     if time.time() - last_save > min_save_time:

@@ -162,3 +162,82 @@ def test_fit_timed_and_philox_mode():
     g1 = sampler.noisy_gradient(kind="pf", N=2000, rng="philox", dtype="f32", subsequence_length=-1)
     g2 = sampler.noisy_gradient(kind="pf", N=2000, rng="philox", dtype="f64", subsequence_length=-1)
     assert all(np.isfinite(vec("svm", g)).all() for g in (g1, g2))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# resident fit (round 4): fit / fit_timed / fit_evaluate with iter_type='SGLD' and pf_kwargs rng='device' run a one-chain
+# ChainEnsemble on the GPU (hipGraph replay of the step), the parameters copied back at the save points
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,S,B", [("svm", 16, 4), ("svm", -1, -1), ("garch", 16, 4), ("lgssm", 8, 2)])
+def test_resident_fit_is_the_chain_ensemble_bitwise(model, S, B):
+    """np.random.seed(s); sampler.fit('SGLD', pf_kwargs=dict(rng='device')) is (seed from np.random, chain 0) of a
+    ChainEnsemble built by hand with the same arguments -- every iterate, bit for bit; the host loop
+    (pf_kwargs resident=False) is still there and is a different (equally valid) trajectory."""
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd.models.svm import SVMSampler, generate_svm_data
+    from sgmcmc_ssm_amd.models.garch import GARCHSampler, generate_garch_data
+    from sgmcmc_ssm_amd.models.lgssm import LGSSMSampler, generate_lgssm_data
+    Sampler, gen = {"svm": (SVMSampler, generate_svm_data), "garch": (GARCHSampler, generate_garch_data),
+                    "lgssm": (LGSSMSampler, generate_lgssm_data)}[model]
+    np.random.seed(3)
+    p = default_params(model)
+    y = gen(T=200, parameters=p)["observations"]
+    eps = 0.01 if model == "garch" else 0.05
+    kw = dict(iter_type="SGLD", epsilon=eps, subsequence_length=S, buffer_length=B, kind="pf",
+              pf_kwargs=dict(pf="poyiadjis_N", N=300, rng="device"))
+    sampler = Sampler(n=1, m=1, observations=y, parameters=p.copy())
+    assert sampler._resident_plan("SGLD", kw) is not None
+    np.random.seed(77)
+    hist = sampler.fit(num_iters=9, output_all=True, **kw)
+    assert len(hist) == 10 and np.array_equal(hist[0].theta(), p.theta())
+    assert np.array_equal(sampler.parameters.theta(), hist[-1].theta())
+    # the same ensemble by hand: the seed is the two randint draws fit() takes from np.random
+    np.random.seed(77)
+    seed = int(np.random.randint(0, 2 ** 31 - 1)) | (int(np.random.randint(0, 2 ** 31 - 1)) << 31)
+    ens = ChainEnsemble(model, y, p.copy(), num_chains=1, N=300, pf="poyiadjis_N", epsilon=eps, prior=sampler.prior,
+                        subsequence_length=S, buffer_length=B, seed=seed, chain_offset=0,
+                        forward_message=getattr(sampler, "forward_message", None), window_sampling="device")
+    ref = ens.run(9, thin=1)
+    got = np.array([h.theta() for h in hist[1:]])
+    assert np.array_equal(got, ref[:, 0, :got.shape[1]]), (got, ref)
+    assert np.all(np.isfinite(got))
+    # final-only fit: one graph replay of nine steps -> the ninth iterate
+    sampler2 = Sampler(n=1, m=1, observations=y, parameters=p.copy())
+    np.random.seed(77)
+    last = sampler2.fit(num_iters=9, **kw)
+    assert np.array_equal(last.theta(), hist[-1].theta())
+    # the host loop is untouched by rng='replay' and can still be asked for
+    kw_host = dict(kw, pf_kwargs=dict(kw["pf_kwargs"], resident=False))
+    assert sampler._resident_plan("SGLD", kw_host) is None
+    assert sampler._resident_plan("SGLD", dict(kw, pf_kwargs=dict(pf="poyiadjis_N", N=300))) is None          # rng='replay'
+    assert sampler._resident_plan("SGD", kw) is None and sampler._resident_plan("SGLD", dict(kw, minibatch_size=2)) is None
+
+
+def test_resident_fit_timed_and_seq_sampler():
+    """fit_timed on the resident path: (parameters, times) at the reference's save points; a sequence list with
+    num_sequences = 1 (the exchange-rate demos' call, exchange_rate_full_demo.py:96-103) runs resident too (host-side
+    window sampling, no graph); num_sequences = -1 keeps the host loop."""
+    from sgmcmc_ssm_amd.models.svm import SVMSampler, SeqSVMSampler, generate_svm_data
+    np.random.seed(5)
+    p = default_params("svm")
+    y = generate_svm_data(T=400, parameters=p)["observations"]
+    sampler = SVMSampler(n=1, m=1, observations=y, parameters=p.copy())
+    plist, times = sampler.fit_timed(iter_type="SGLD", epsilon=0.05, subsequence_length=16, buffer_length=4, kind="pf",
+                                     pf_kwargs=dict(pf="poyiadjis_N", N=500, rng="device"), max_time=0.6, min_save_time=0.1)
+    assert len(plist) == len(times) >= 3 and times[0] == 0.0 and all(b > a for a, b in zip(times, times[1:]))
+    assert all(np.all(np.isfinite(q.theta())) for q in plist)
+    assert not np.array_equal(plist[-1].theta(), plist[0].theta())
+    pl, tm, metrics = sampler.fit_evaluate(iter_type="SGLD", epsilon=0.05, subsequence_length=16, buffer_length=4, kind="pf",
+                                           pf_kwargs=dict(pf="poyiadjis_N", N=500, rng="device"), max_time=0.3, min_save_time=0.1,
+                                           metric_functions=lambda s: dict(metric="A", variable="A", value=float(s.parameters.A[0, 0])))
+    assert list(pl["iteration"]) == list(tm["iteration"]) and pl["iteration"].iloc[-1] >= 64          # >= one burst per save
+    assert len(metrics) == len(pl)
+    segs = [y[k * 80:(k + 1) * 80] for k in range(5)]
+    seq = SeqSVMSampler(n=1, m=1, observations=segs, parameters=p.copy())
+    kw = dict(iter_type="SGLD", epsilon=0.01, subsequence_length=16, buffer_length=4, kind="pf",
+              pf_kwargs=dict(pf="poyiadjis_N", N=500, rng="device"))
+    assert seq._resident_plan("SGLD", dict(kw, num_sequences=1)) is not None
+    assert seq._resident_plan("SGLD", dict(kw, num_sequences=-1)) is None
+    np.random.seed(8)
+    h = seq.fit(num_iters=5, output_all=True, num_sequences=1, **kw)
+    assert len(h) == 6 and all(np.all(np.isfinite(q.theta())) for q in h)

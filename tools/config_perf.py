@@ -93,6 +93,23 @@ if which == "dropin":
             s.sample_sgld(epsilon=0.01, **kw); s.project_parameters()
         dt = (time.perf_counter() - t0) / n
         print(f"drop-in SVMSampler.sample_sgld N=1000 {name:28s}: {dt*1e3:8.3f} ms/step  {1/dt:8.1f} steps/s", flush=True)
+if which == "dropin_fit":
+    # fit() on the resident path (rng='device': one-chain ChainEnsemble, hipGraph replay) against the host loop
+    from sgmcmc_ssm_amd.models.svm import SVMSampler
+    np.random.seed(1)
+    p, gen = params("svm")
+    y = gen(T=1000, parameters=p)["observations"]
+    for S, B, name in ((16, 4, "S=16 B=4"), (-1, -1, "full T=1000")):
+        for resident in (False, True):
+            s = SVMSampler(n=1, m=1, observations=y, parameters=p.copy())
+            kw = dict(iter_type="SGLD", epsilon=0.01, subsequence_length=S, buffer_length=B, kind="pf",
+                      pf_kwargs=dict(pf="poyiadjis_N", N=1000, rng="device", resident=resident))
+            s.fit(num_iters=64, **kw)
+            n = 2048 if S != -1 else 128
+            t0 = time.perf_counter()
+            s.fit(num_iters=n, **kw)
+            dt = (time.perf_counter() - t0) / n
+            print(f"drop-in SVMSampler.fit SGLD N=1000 {name:12s} rng=device {'resident' if resident else 'host loop':9s}: {dt*1e3:8.4f} ms/step  {1/dt:9.1f} steps/s", flush=True)
 if which == "dropin_large":
     # BASELINE configs 4 and 5 through the drop-in Sampler API, seed-compatible (rng='replay': pf_mem_kernel) and device rng
     from sgmcmc_ssm_amd.models.svm import SVMSampler, SeqSVMSampler
