@@ -824,6 +824,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
         }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) anc[k] = anc[k] < last ? anc[k] : last;
+#ifdef PFG_EXP_OWNGATHER
+        // knock-out (timing / counters only, NOT a valid resampler): the real search runs (its result is kept alive), but
+        // every child gathers its OWN slot -- conflict-free lane <-> particle reads: what is left of SQ_LDS_BANK_CONFLICT is
+        // the search's share (profiles/r04_lds_conflict_split.txt)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) { asm volatile("" :: "v"(anc[k])); anc[k] = valid[k] ? k * NT + tid : 0; }
+#endif
         if (RNG == PFG_RNG_REPLAY) {
             // near-tie margin: how close u came to flipping an ancestor index
 #pragma unroll

@@ -16,12 +16,12 @@ PROF = os.path.join(ROOT, "profiles")
 
 @pytest.mark.parametrize("cfg", ["c1", "c2", "c3", "c4", "c5"])
 def test_profiles_match_bench_line(cfg):
-    line = json.load(open(os.path.join(PROF, "r03_{0}_bench.json".format(cfg))))
+    line = json.load(open(os.path.join(PROF, "r04_{0}_bench.json".format(cfg))))
     variant, chains, dtype = line["config"]["kernel_variant"], line["config"]["chains_per_gpu"], line["dtype"]
     assert chains == bench.CONFIGS[cfg][5]                    # profiled at the bench's default batch size
     key = "{0}_{1}_{2}".format(cfg, dtype, variant)
     kern_ms = line["roofline"]["kernel_ms"]
-    rows = list(csv.DictReader(open(os.path.join(PROF, "r03_{0}_kernel_stats.csv".format(cfg)))))
+    rows = list(csv.DictReader(open(os.path.join(PROF, "r04_{0}_kernel_stats.csv".format(cfg)))))
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     assert ("pf_big_kernel" if variant.startswith("big") else "pf_reg_kernel") in top["Name"]
     assert abs(float(top["AverageNs"]) * 1e-6 - kern_ms) < 0.05 * kern_ms      # rocprofv3 vs HIP events
@@ -41,8 +41,12 @@ def test_profiles_match_bench_line(cfg):
     l = bench.lds_roofline(key, chains, kern_ms, clock)
     assert r is not None and 0.25 < r["frac"] < 1.0 and r["frac_vs_measured_streams"] > r["frac"]
     assert l is not None and 0.25 < l["frac"] < 1.0 and 0.0 < l["bank_conflict_share"] < 0.7
-    top, name = (l, "lds") if l["frac"] > r["frac"] else (r, "valu")
-    assert line["roofline"]["bound"] == name and abs(line["roofline"]["frac"] - top["frac"]) < 2e-3
+    # `bound` = the pipe with the highest USEFUL utilisation (LDS: conflict-free cycles), the busier pipe beside it
+    useful_lds = l["frac_conflict_free"]
+    name, frac = ("lds", useful_lds) if useful_lds > r["frac"] else ("valu", r["frac"])
+    assert line["roofline"]["bound"] == name and abs(line["roofline"]["frac"] - frac) < 2e-3
+    assert line["roofline"]["busiest_pipe"] == ("lds" if l["frac"] > r["frac"] else "valu")
+    assert abs(line["roofline"]["busiest_pipe_busy_frac"] - max(l["frac"], r["frac"])) < 2e-3
     assert traffic[key]["bytes_per_launch"] < 0.01 * line["roofline"]["hbm_model"]["algorithmic_bytes_per_launch"]
 
 
