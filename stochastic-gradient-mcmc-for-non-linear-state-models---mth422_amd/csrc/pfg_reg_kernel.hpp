@@ -499,7 +499,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             }
         }
         double wave_inc = 0.0;          // BLK: this wave's inclusive scan (lane 63 = the wave total)
-        double es[PPT];                 // SORTED: inclusive prefix of the exponential spacings of this thread's children
+        float es[PPT];                  // SORTED: inclusive prefix of the exponential spacings of this thread's children (in-wave
+                                        // sums < 2^9 in f32: good to 1e-5 of a spacing, half the registers across barrier 2 and a
+                                        // 6-instruction wave scan; the cross-wave offsets and the normalisation are f64)
         uint32_t us[PPT];               // SORTED: the sorted uniforms as 32-bit fixed point
         if (BLK) {
 #pragma unroll
@@ -515,14 +517,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 // (N+1)-th spacing rides in the last wave's total
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const double e = (double)spacing_f32(rng.next());
-                    es[k] = (valid[k] ? e : 0.0) + (k > 0 ? es[k - 1] : 0.0);
+                    const float e = spacing_f32(rng.next());
+                    es[k] = (valid[k] ? e : 0.0f) + (k > 0 ? es[k - 1] : 0.0f);
                 }
-                double einc = wave_incl_scan(es[PPT - 1]);
-                const double eexc = einc - es[PPT - 1];
+                const float eincf = wave_incl_scan_f32(es[PPT - 1]);
+                const float eexc = eincf - es[PPT - 1];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) es[k] += eexc;
                 if (lane == WAVE - 1) {
+                    double einc = (double)eincf;
                     if (wave == NW - 1) einc += (double)spacing_f32(rng.next());
                     red_scan[NW + wave] = einc;
                 }
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 r = fma(fma(-Etot, r, 1.0), r, r);
                 const double fe = uniform_f64(r * 4294967296.0);
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) us[k] = cvt_u32_sat((es[k] + offE) * fe);
+                for (int k = 0; k < PPT; ++k) us[k] = cvt_u32_sat(((double)es[k] + offE) * fe);
             }
         } else if (PPT * NW <= 16) {
             // lane j < PPT*NW holds total j; exclusive prefix by a 16-lane DPP scan; each thread

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 passes of tools/r03_profiles.sh (gpurun_out/<tag>_prof/<config>/) into the
+"""Condense the rocprofv3 passes of tools/r04_profiles.sh (gpurun_out/<tag>_prof/<config>/) into the
 tracked files bench.py and the judge read:
   profiles/<tag>_<config>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
   profiles/<tag>_<config>_bench.json         the bench line of the traced run
@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-cfgs = sys.argv[2:] or ["c1", "c2", "c3", "c4", "c5"]
+cfgs = sys.argv[2:] or ["c1", "c2", "c3", "c4", "c5", "g1"]
 PROF = os.path.join(ROOT, "profiles")
 
 
@@ -36,7 +36,8 @@ for c in cfgs:
     src = os.path.join(ROOT, "gpurun_out", tag + "_prof", c)
     line = json.loads([l for l in open(os.path.join(src, "bench_trace.json")) if l.startswith("{")][-1])
     variant, chains, dtype = line["config"]["kernel_variant"], line["config"]["chains_per_gpu"], line["dtype"]
-    ksub = "pf_big_kernel" if variant.startswith("big") else ("pf_mem_kernel" if variant.startswith("mem") else "pf_reg_kernel")
+    ksub = ("pf_big_kernel" if variant.startswith("big") else "pf_mem_kernel" if variant.startswith("mem")
+            else "pfg_grid_step_dev_kernel" if variant.startswith("grid") else "pf_reg_kernel")
     shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(PROF, "{0}_{1}_kernel_stats.csv".format(tag, c)))
     json.dump(line, open(os.path.join(PROF, "{0}_{1}_bench.json".format(tag, c)), "w"), indent=1)
     key = "{0}_{1}_{2}".format(c, dtype, variant)
@@ -97,9 +98,16 @@ for c in cfgs:
         vr = bench.valu_roofline(key, chains, roof["kernel_ms"], roof["in_kernel_clock_ghz"])
         lr = bench.lds_roofline(key, chains, roof["kernel_ms"], roof["in_kernel_clock_ghz"])
         if vr:
-            top, name = (lr, "lds") if (lr and lr["frac"] > vr["frac"]) else (vr, "valu")
-            roof.update(bound=name, achieved=top["achieved"], peak=top["peak"], frac=top["frac"], valu=vr, lds=lr,
-                        unit="G LDS-array cycles/s" if name == "lds" else "G VALU issue-cycles/s")
+            # bench.py's rule: the pipe with the highest USEFUL utilisation (LDS: conflict-free cycles), the busier pipe beside it
+            useful = lr["frac_conflict_free"] if lr else 0.0
+            lds_binds = bool(lr and useful > vr["frac"])
+            roof.update(bound="lds" if lds_binds else "valu",
+                        achieved=(lr["achieved"] * (1.0 - lr["bank_conflict_share"])) if lds_binds else vr["achieved"],
+                        peak=(lr if lds_binds else vr)["peak"], frac=useful if lds_binds else vr["frac"], valu=vr, lds=lr,
+                        lds_frac_conflict_free=useful if lr else None,
+                        busiest_pipe=("lds" if (lr and lr["frac"] > vr["frac"]) else "valu"),
+                        busiest_pipe_busy_frac=max(lr["frac"], vr["frac"]) if lr else vr["frac"],
+                        unit="G conflict-free LDS-array cycles/s" if lds_binds else "G VALU issue-cycles/s")
     roof["stale"] = False
     roof.pop("stale_note", None)
     roof["counters"] = "restated by tools/make_profiles.py with the PMC passes of this same profile run"
