@@ -246,6 +246,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const int NLS = NL + (FAST ? state_pad<REAL, RNG>() : 0);
     const size_t bufsz = (size_t)(NS + H) * NLS;
     REAL *cur = buf0, *nxt = PP ? buf0 + bufsz : buf0;
+    // PAIRED (round 4; the device-generator production kernels in fp64 with an even record length: SVM, GARCH): the state
+    // is stored as (NS + H) / 2 arrays of 16-byte PAIRS {component 2p, component 2p + 1} instead of NS + H arrays of
+    // doubles.  The parent gathers -- 16 random ds_read_b64 per lane-timestep of the SVM kernel, 56 % of its LDS
+    // bank-conflict cycles (profiles/r04_lds_conflict_split.txt) -- become 8 ds_read_b128, which use the full width of
+    // the LDS; the children's stores stay lane-contiguous (ds_write_b128).  -DPFG_OPT_PAIRSTATE=0 restores the arrays.
+#ifndef PFG_OPT_PAIRSTATE
+#define PFG_OPT_PAIRSTATE 1
+#endif
+    constexpr bool PAIRED = PFG_OPT_PAIRSTATE && BLK && sizeof(REAL) == 8 && ((NS + H) % 2 == 0);
+    // element index of component d of particle i
+    auto sidx = [&](int d, int i) -> size_t {
+        return PAIRED ? (size_t)(d >> 1) * (2 * (size_t)NLS) + 2 * (size_t)i + (size_t)(d & 1) : (size_t)d * NLS + (size_t)i;
+    };
     double *red = reinterpret_cast<double *>(buf0 + (PP ? 2 : 1) * bufsz);
     double *red_scan = red;                 // [PPT*NW]
     double *red_max = red + PPT * NW;       // [NW]
@@ -414,9 +427,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     if (RNG == PFG_RNG_DEVICE && PFG_TR(P.trace_x) && P.rec_z0) P.rec_z0[i] = z;
                 }
 #pragma unroll
-                for (int d = 0; d < NS; ++d) cur[(size_t)d * NLS + i] = x[d];
+                for (int d = 0; d < NS; ++d) cur[sidx(d, i)] = x[d];
 #pragma unroll
-                for (int h = 0; h < H; ++h) cur[(size_t)(NS + h) * NLS + i] = s[h];
+                for (int h = 0; h < H; ++h) cur[sidx((NS + h), i)] = s[h];
                 if (PFG_TR(P.trace_x)) {
 #pragma unroll
                     for (int d = 0; d < NS; ++d) P.trace_x[(size_t)i * NS + d] = (double)x[d];
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int h = 0; h < H; ++h) {
                 double part = 0.0;
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) part += (double)cur[(size_t)(NS + h) * NLS + own[k]] * cs[k];
+                for (int k = 0; k < PPT; ++k) part += (double)cur[sidx((NS + h), own[k])] * cs[k];
                 part = wave_sum(part);
                 if (lane == 0) red_S[h * NW + wave] = part;
             }
@@ -852,10 +865,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             REAL xp[PPT][NS], sp[PPT][H];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
+                if constexpr (PAIRED) {
+                    typedef double dv2 __attribute__((ext_vector_type(2)));
+                    REAL rec[NS + H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[k][d] = cur[(size_t)d * NLS + anc[k]];
+                    for (int p = 0; p < (NS + H) / 2; ++p) {
+                        const dv2 v = *reinterpret_cast<const dv2 *>(&cur[sidx(2 * p, anc[k])]);
+                        rec[2 * p] = (REAL)v.x; rec[2 * p + 1] = (REAL)v.y;
+                    }
 #pragma unroll
-                for (int h = 0; h < H; ++h) sp[k][h] = cur[(size_t)(NS + h) * NLS + anc[k]];
+                    for (int d = 0; d < NS; ++d) xp[k][d] = rec[d];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) sp[k][h] = rec[NS + h];
+                } else {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) xp[k][d] = cur[sidx(d, anc[k])];
+#pragma unroll
+                for (int h = 0; h < H; ++h) sp[k][h] = cur[sidx((NS + h), anc[k])];
+                }
             }
             PFG_PH(7)
             if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
@@ -899,10 +926,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     // spilled registers at the 128-VGPR cap, 13.1 instead of 14.5 ms per config-4 launch)
                     if ((FAST && NT < 1024) || valid[k]) {
                         const int i = k * NT + tid;
+                        if constexpr (PAIRED) {
+                            typedef double dv2 __attribute__((ext_vector_type(2)));
+                            REAL rec[NS + H];
 #pragma unroll
-                        for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + i] = xn[d];
+                            for (int d = 0; d < NS; ++d) rec[d] = xn[d];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + i] = sp[k][h];
+                            for (int h = 0; h < H; ++h) rec[NS + h] = sp[k][h];
+#pragma unroll
+                            for (int p = 0; p < (NS + H) / 2; ++p) {
+                                dv2 v;
+                                v.x = (double)rec[2 * p]; v.y = (double)rec[2 * p + 1];
+                                *reinterpret_cast<dv2 *>(&nxt[sidx(2 * p, i)]) = v;
+                            }
+                        } else {
+#pragma unroll
+                        for (int d = 0; d < NS; ++d) nxt[sidx(d, i)] = xn[d];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) nxt[sidx((NS + h), i)] = sp[k][h];
+                        }
                     }
                 }
             };
@@ -929,14 +971,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) {
                 REAL xp[NS], add[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NLS + anc[k]];
+                for (int d = 0; d < NS; ++d) xp[d] = cur[sidx(d, anc[k])];
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
                 aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
 #pragma unroll
                 for (int h = 0; h < H; ++h) sacc[k][h] = (REAL)0;
                 if (valid[k]) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + k * NT + tid] = xn[k][d];
+                    for (int d = 0; d < NS; ++d) nxt[sidx(d, k * NT + tid)] = xn[k][d];
                 }
             }
             // wave-local work queues of pending children (this wave's NT*PPT/NW slots of two [NL]
@@ -979,7 +1021,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     I = I < last ? I : last;
                     REAL xI[NS], xc[NS];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) { xI[d] = cur[(size_t)d * NLS + I]; xc[d] = nxt[(size_t)d * NLS + child]; }
+                    for (int d = 0; d < NS; ++d) { xI[d] = cur[sidx(d, I)]; xc[d] = nxt[sidx(d, child)]; }
                     const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xc));
                     Iout = I;
                     return act && u2 <= thr;
@@ -1094,7 +1136,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                             I = I < last ? I : last;
                             REAL xI[NS];
 #pragma unroll
-                            for (int d = 0; d < NS; ++d) xI[d] = cur[(size_t)d * NLS + I];
+                            for (int d = 0; d < NS; ++d) xI[d] = cur[sidx(d, I)];
                             const double thr = (double)mth.exp(backward_log_ratio<MODEL, REAL>(c, mth, xI, xn[k]));
                             if (pend[k] && u2v[k] <= thr) { Jres[k * NT + tid] = I; pend[k] = false; }
                         }
@@ -1110,7 +1152,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                             const int i = k * NT + tid;
                             queue[rank[k]] = i;
                             const double um = noar ? strm[paris_cursor + (long long)i * Nt + j] : strm[paris_cursor + rank[k]];
-                            nxt[(size_t)NS * NLS + i] = (REAL)um;
+                            nxt[sidx(NS, i)] = (REAL)um;
                         }
                         if (tid == 0) *qcount = S;
                         if (!noar) paris_cursor += S;
@@ -1128,7 +1170,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         // the child's fallback uniform rides in its (still unused) statistic slot
                         const double um = (RNG == PFG_RNG_REPLAY) ? pman[((size_t)t * Nt + j) * N + i]
                                                                   : u01_32(rng.next());
-                        nxt[(size_t)NS * NLS + i] = (REAL)um;
+                        nxt[sidx(NS, i)] = (REAL)um;
                     }
                 }
                 __syncthreads();
@@ -1141,8 +1183,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     const int ci = queue[e];
                     REAL xc[NS];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xc[d] = nxt[(size_t)d * NLS + ci];
-                    const double um = (double)nxt[(size_t)NS * NLS + ci];
+                    for (int d = 0; d < NS; ++d) xc[d] = nxt[sidx(d, ci)];
+                    const double um = (double)nxt[sidx(NS, ci)];
                     if constexpr (RNG == PFG_RNG_DEVICE) {
                         // Device generator: any enumeration of the parents is a valid categorical
                         // sampler, so enumerate LANE-major (lane's parents lane, lane+64, ...): per-lane
@@ -1160,7 +1202,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                             const int qq = q < N ? q : last;
                             REAL xq[NS];
 #pragma unroll
-                            for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NLS + qq];
+                            for (int d = 0; d < NS; ++d) xq[d] = cur[sidx(d, qq)];
                             lq[mI] = (q < N && mI < nchunk) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc)
                                                             : (REAL)(-INFINITY);
                             mxf2 = fmaxf(mxf2, (float)lq[mI]);
@@ -1200,7 +1242,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         const int qq = q < N ? q : last;
                         REAL xq[NS];
 #pragma unroll
-                        for (int d = 0; d < NS; ++d) xq[d] = cur[(size_t)d * NLS + qq];
+                        for (int d = 0; d < NS; ++d) xq[d] = cur[sidx(d, qq)];
                         l[mI] = (q < N) ? lwL[qq] + backward_log_ratio<MODEL, REAL>(c, mth, xq, xc) : (REAL)(-INFINITY);
                         mxf = fmaxf(mxf, (float)l[mI]);
                         if (mI + 1 >= nchunk) break;
@@ -1240,12 +1282,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                         P.trace_paris_J[((size_t)t * Nt + j) * N + k * NT + tid] = Jk;
                     REAL xJ[NS], aj[H];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) xJ[d] = cur[(size_t)d * NLS + Jk];
+                    for (int d = 0; d < NS; ++d) xJ[d] = cur[sidx(d, Jk)];
                     additive_stat<MODEL, STAT, REAL>(c, xJ, xn[k], (REAL)y_t, aux[k], aj);
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
                         const REAL a = use_stat ? aj[h] * (REAL)wt : (REAL)0;
-                        sacc[k][h] += cur[(size_t)(NS + h) * NLS + Jk] + a;
+                        sacc[k][h] += cur[sidx((NS + h), Jk)] + a;
                     }
                 }
                 __syncthreads();                // queue / statistic-slot scratch free for the next j
@@ -1256,7 +1298,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
                 if (valid[k]) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + k * NT + tid] = sacc[k][h] / (REAL)Nt;
+                    for (int h = 0; h < H; ++h) nxt[sidx((NS + h), k * NT + tid)] = sacc[k][h] / (REAL)Nt;
                 }
             }
         };
@@ -1272,12 +1314,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int k = 0; k < PPT; ++k) {
                 REAL xp[NS], add[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xp[d] = cur[(size_t)d * NLS + anc[k]];
+                for (int d = 0; d < NS; ++d) xp[d] = cur[sidx(d, anc[k])];
                 particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zz[k], xn[k], lwn[k], add);
                 aux[k] = (MODEL == PFG_MODEL_SVM) ? mth.exp(-xn[k][0]) : (REAL)0;
                 if (valid[k]) {
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) nxt[(size_t)d * NLS + k * NT + tid] = xn[k][d];
+                    for (int d = 0; d < NS; ++d) nxt[sidx(d, k * NT + tid)] = xn[k][d];
                 }
             }
             REAL mx[PPT];
@@ -1287,7 +1329,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int j = 0; j < N; ++j) {
                 REAL xj[NS];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NLS + j];
+                for (int d = 0; d < NS; ++d) xj[d] = cur[sidx(d, j)];
                 const REAL lj = lwL[j];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
@@ -1306,9 +1348,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             for (int j = 0; j < N; ++j) {
                 REAL xj[NS], sj[H];
 #pragma unroll
-                for (int d = 0; d < NS; ++d) xj[d] = cur[(size_t)d * NLS + j];
+                for (int d = 0; d < NS; ++d) xj[d] = cur[sidx(d, j)];
 #pragma unroll
-                for (int h = 0; h < H; ++h) sj[h] = cur[(size_t)(NS + h) * NLS + j];
+                for (int h = 0; h < H; ++h) sj[h] = cur[sidx((NS + h), j)];
                 const REAL lj = lwL[j];
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
@@ -1328,7 +1370,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                 lw[k] = valid[k] ? lwn[k] : (REAL)(-INFINITY);
                 if (valid[k]) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) nxt[(size_t)(NS + h) * NLS + k * NT + tid] = num[k][h] / den[k];
+                    for (int h = 0; h < H; ++h) nxt[sidx((NS + h), k * NT + tid)] = num[k][h] / den[k];
                 }
             }
         };
@@ -1358,12 +1400,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
                     const size_t row = (size_t)(t + 1) * N + i;
                     if (P.trace_anc) P.trace_anc[(size_t)t * N + i] = anc[k];
 #pragma unroll
-                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[(size_t)d * NLS + i];
+                    for (int d = 0; d < NS; ++d) P.trace_x[row * NS + d] = (double)nxt[sidx(d, i)];
                     P.trace_logw[row] = (double)lw[k];
                     if (P.trace_stats && !is_filter) {
 #pragma unroll
                         for (int h = 0; h < H; ++h)
-                            P.trace_stats[row * H + h] = (double)nxt[(size_t)(NS + h) * NLS + i];
+                            P.trace_stats[row * H + h] = (double)nxt[sidx((NS + h), i)];
                     }
                 }
             }
@@ -1413,12 +1455,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
             const int i = k * NT + tid;
             if (i < N) {
 #pragma unroll
-                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[(size_t)d * NLS + i];
+                for (int d = 0; d < NS; ++d) P.final_x[(size_t)i * NS + d] = (double)cur[sidx(d, i)];
                 if (P.final_logw) P.final_logw[i] = (double)lw[k];
                 if (P.final_stats && !is_filter) {
 #pragma unroll
                     for (int h = 0; h < H; ++h)
-                        P.final_stats[(size_t)i * H + h] = (double)cur[(size_t)(NS + h) * NLS + i];
+                        P.final_stats[(size_t)i * H + h] = (double)cur[sidx((NS + h), i)];
                 }
             }
         }
