@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 122          /* 0.1.22 */
+#define PFG_VERSION 123          /* 0.1.23 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -139,7 +139,7 @@ typedef struct pfg_problem {
      * as sgmcmc_ssm_amd.particle_filters does.  A window of several timesteps carries the cursor from one timestep to
      * the next (PARIS_NO_ACCEPT_REJECT: child i's draw j at timestep t reads double (t N + i) Ntilde + j): given the
      * concatenation of what the single-timestep calls consumed it repeats them in one launch (with `elementwise`).
-     * PFG_FLAG_PARIS_RAW_STREAM (N <= 1024): z0 / u / z are NULL and paris_stream holds what RandomState.random_sample
+     * PFG_FLAG_PARIS_RAW_STREAM (dtype f64; N <= 16384): z0 / u / z are NULL and paris_stream holds what RandomState.random_sample
      * delivers from the generator's current state: the kernel takes EVERYTHING from it in np.random's order -- N normals
      * for x0, then per timestep N uniforms, N normals and the backward sampling's uniforms -- so a whole window is one
      * launch.  The normals are NumPy's legacy Gaussians (Marsaglia's polar method on pairs of doubles, second variate of

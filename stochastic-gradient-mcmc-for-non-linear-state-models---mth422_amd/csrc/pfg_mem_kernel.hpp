@@ -90,9 +90,11 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     const pfg_dev_problem &P = probs[blockIdx.x];
     const int N = P.N, T = P.T, t1 = P.t1, tL = P.tL;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    if (PARIS && (P.flags & PFG_FLAG_PARIS_RAW_STREAM)) {
-        // the whole-window stream is understood by the LDS-resident PaRIS kernel only (N <= 1024): a descriptor that asks
-        // for it here has no u / z to fall back on -- report "stream too short" instead of reading NULL
+    // PFG_FLAG_PARIS_RAW_STREAM (the window's whole np.random stream, see pfgrad.h): the fp64 REPLAY instantiation takes it
+    // (round 4: one launch per window for 1024 < N <= 16384 too); any other instantiation has no u / z to fall back on and
+    // reports "stream too short" instead of reading NULL
+    constexpr bool RAWCAP = PARIS && RNG == PFG_RNG_REPLAY && sizeof(REAL) == 8;
+    if (PARIS && !RAWCAP && (P.flags & PFG_FLAG_PARIS_RAW_STREAM)) {
         if (tid == 0 && P.paris_consumed) P.paris_consumed[0] = -1ll;
         return;
     }
@@ -156,6 +158,83 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     if (RNG == PFG_RNG_DEVICE)
         rng = lane_rng_init(P.seed, P.stream, P.step_ctr ? *P.step_ctr : 0ull, (uint32_t)tid);
 
+    // ---- PaRIS, the reference's whole np.random stream in ONE launch (as pf_reg_kernel does for N <= 1024) ---------------
+    // The N normals of a call are NumPy's legacy Gaussians -- Marsaglia's polar method on pairs of doubles, the second
+    // variate of a pair cached for the next draw --, generated here from the raw doubles: attempts are evaluated NT * 4 at a
+    // time, the accepted ones ranked in stream order by a workgroup-wide count, the q-th accepted pair fills normals 2q and
+    // 2q + 1 of the call, the attempt that completes the call moves the cursor.  Accept / reject is exact fp64 arithmetic
+    // (no contraction in the REPLAY units): the CONSUMPTION is the reference's to the double; the values go through the
+    // device's log (<= 1 ulp from the host libm's: REPLAY tolerance).
+    long long paris_cursor = 0;            // doubles of P.paris_stream consumed so far
+    bool paris_overflow = false;
+    const bool raw = RAWCAP && (P.flags & PFG_FLAG_PARIS_RAW_STREAM) != 0 && P.paris_stream != nullptr;
+    bool carry_has = false;                // a cached second variate is pending (workgroup-uniform); its value sits in red_W[2]
+    double *const zbuf = reinterpret_cast<double *>(qum);                   // [N] normals of the current call (the fallback queue's uniforms are not in use then)
+    long long *const raw_slots = reinterpret_cast<long long *>(red_W + 3);  // [0] cut-off attempt of a call, [1] stream position of the cached pair
+    [[maybe_unused]] auto legacy_normals = [&]() __attribute__((noinline)) {
+        constexpr int RPT = 4;
+        const gptr<const double> strm = global_ptr(P.paris_stream);
+        const long long cap = P.paris_stream_len;
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        int *const wc = reinterpret_cast<int *>(red_scan);                 // [RPT][NW] accepted attempts per (slot, wave)
+        const int produced0 = carry_has ? 1 : 0;
+        __syncthreads();
+        if (carry_has && tid == 0) zbuf[0] = red_W[2];
+        const int need = (N - produced0 + 1) >> 1;                         // pairs to accept
+        const long long base = paris_cursor;
+        int acc = 0;
+        for (int round = 0; acc < need && !paris_overflow; ++round) {
+            double x1[RPT], x2[RPT], r2[RPT];
+            bool fl[RPT];
+            int rank[RPT];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const long long p = base + 2 * ((long long)round * (NT * RPT) + k * NT + tid);
+                const bool in = p + 1 < cap;
+                const double d0 = in ? strm[p] : 0.5, d1 = in ? strm[p + 1] : 0.5;
+                x1[k] = 2.0 * d0 - 1.0;
+                x2[k] = 2.0 * d1 - 1.0;
+                r2[k] = x1[k] * x1[k] + x2[k] * x2[k];
+                fl[k] = in && !(r2[k] >= 1.0 || r2[k] == 0.0);
+                const unsigned long long mk = __ballot(fl[k]);
+                rank[k] = __popcll(mk & ltm);
+                if (lane == 0) wc[k * NW + wave] = __popcll(mk);
+            }
+            __syncthreads();
+            int Sacc = 0;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                for (int w = 0; w < NW; ++w) {
+                    if (w == wave) rank[k] += Sacc;
+                    Sacc += wc[k * NW + w];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int q = acc + rank[k];
+                if (fl[k] && q < need) {
+                    const double f = ::sqrt(-2.0 * ::log(r2[k]) / r2[k]);
+                    const int i0 = produced0 + 2 * q;
+                    zbuf[i0] = f * x2[k];                                  // returned by this call of legacy_gauss
+                    const long long j = (long long)round * (NT * RPT) + k * NT + tid;
+                    if (i0 + 1 < N) zbuf[i0 + 1] = f * x1[k];              // the cached one, returned by the next call
+                    else { red_W[2] = f * x1[k]; raw_slots[1] = base + 2 * j; }
+                    if (q == need - 1) raw_slots[0] = j;
+                }
+            }
+            acc += Sacc;
+            if (acc < need && base + 2 * ((long long)(round + 1) * (NT * RPT)) + 1 >= cap) paris_overflow = true;
+            __syncthreads();
+        }
+        if (need > 0 && !paris_overflow) paris_cursor = base + 2 * (raw_slots[0] + 1);
+        carry_has = ((N - produced0) & 1) != 0;
+    };
+    if (RAWCAP && raw && (P.flags & PFG_FLAG_PARIS_RAW_CARRY)) {          // the generator came with a cached Gaussian: stream[0]
+        carry_has = true;
+        if (tid == 0) red_W[2] = P.paris_stream[0];
+        paris_cursor = 1;
+    }
+    if constexpr (RAWCAP) { if (raw && !P.init_x) legacy_normals(); }
     REAL lwr[4];                                                    // LW4: this thread's log-weights (slots past N: -inf)
 #pragma unroll
     for (int q = 0; q < 4; ++q) lwr[q] = (REAL)(-INFINITY);
@@ -183,7 +262,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 }
             } else {
                 double z;
-                if (RNG == PFG_RNG_REPLAY) z = P.z0[i];
+                if (RNG == PFG_RNG_REPLAY) z = (RAWCAP && raw) ? zbuf[i] : P.z0[i];
                 else { REAL a, b; mth.normal_pair(rng.next(), rng.next(), a, b); z = (double)a; }
                 x[0] = (REAL)(P.prior_mean + sd * z);
             }
@@ -213,8 +292,6 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     __syncthreads();
 
     double ll = 0.0, wt_prev = 1.0, tie = 1.0;
-    long long paris_cursor = 0;            // PaRIS in the reference's stream order (see pf_reg_kernel): doubles consumed
-    bool paris_overflow = false;
     double filt[H], S[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) { filt[h] = 0.0; S[h] = 0.0; }
@@ -572,6 +649,18 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 int a = pos - pos / 33;
                 return a < N - 1 ? a : N - 1;
             };
+            // whole-window stream: this timestep's N resampling uniforms sit at the cursor, the N normals of Kernel.rv behind
+            // them (legacy Gaussians from the raw doubles), then the backward sampling's run
+            long long cursor_u = 0;
+            if constexpr (RAWCAP) {
+                if (raw) {
+                    cursor_u = paris_cursor;
+                    if (paris_cursor + N > P.paris_stream_len) paris_overflow = true;
+                    paris_cursor += N;
+                    if (!paris_overflow) legacy_normals();
+                    __syncthreads();
+                }
+            }
             // ---- 1. propose every child from its filter ancestor, publish x' and log-weight ----
             for (int j = 0; j < nchunk; ++j) {
                 const int i = j * NT + tid;
@@ -579,7 +668,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 const int ii = v ? i : N - 1;
                 double u;
                 REAL z;
-                if (RNG == PFG_RNG_REPLAY) { u = uv[(size_t)t * N + ii]; z = (REAL)zv[(size_t)t * N + ii]; }
+                if (RAWCAP && raw) { u = paris_overflow ? 0.5 : P.paris_stream[cursor_u + ii]; z = (REAL)zbuf[ii]; }
+                else if (RNG == PFG_RNG_REPLAY) { u = uv[(size_t)t * N + ii]; z = (REAL)zv[(size_t)t * N + ii]; }
                 else { REAL zb; u = u01_32(rng.next()); mth.normal_pair(rng.next(), rng.next(), z, zb); }
                 const int a = search(u);
                 if (RNG == PFG_RNG_REPLAY && v) {
@@ -694,7 +784,10 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                         __syncthreads();                           // woff / wcnt are rewritten by the next round
                     }
                     if (Stot > 0 && !noar && paris_cursor + Stot > cap) paris_overflow = true;
-                    if (Stot > 0 && noar && (long long)(t + 1) * N * Nt > cap) paris_overflow = true;
+                    // accept_reject = False: child i's draw j reads double i Ntilde + j of the timestep's N Ntilde -- behind the cursor
+                    // in a whole-window stream, at (t N + i) Ntilde + j in a stream of backward draws only
+                    const long long noar_base = (RAWCAP && raw) ? paris_cursor : (long long)t * N * Nt;
+                    if (Stot > 0 && noar && noar_base + (long long)N * Nt > cap) paris_overflow = true;
                     if (!paris_overflow && Stot > 0) {
                         for (int j = 0; j < nchunk; ++j) {
                             const bool pj = (pend >> j) & 1u;
@@ -703,7 +796,7 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                             const int i = j * NT + tid;
                             const int rank = woff[j * NW + wave] + __popcll(mk & ltmask);
                             qchild[rank] = i;
-                            qum[rank] = (REAL)(noar ? strm[((long long)t * N + i) * Nt + jt] : strm[paris_cursor + rank]);
+                            qum[rank] = (REAL)(noar ? strm[noar_base + (long long)i * Nt + jt] : strm[paris_cursor + rank]);
                         }
                         if (tid == 0) *qcount = Stot;
                         if (!noar) paris_cursor += Stot;
@@ -888,6 +981,8 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
                 for (int e = tid; e < nq; e += NT) contribute(qchild[e], qres[e]);
                 __syncthreads();
             }
+            if (RAWCAP && raw && (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) && !paris_overflow)
+                paris_cursor += (long long)N * Nt;            // accept_reject = False in a whole-window stream: the timestep's N Ntilde draws
             // ---- 5. average over the Ntilde draws, traces -----------------------------------------
             for (int j = 0; j < nchunk; ++j) {
                 const int i = j * NT + tid;
@@ -1028,8 +1123,9 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
         for (int w = 1; w < NW; ++w) tie = red_max[w] < tie ? red_max[w] : tie;
     }
     if (PARIS && tid == 0 && P.paris_consumed) {
-        if (P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) paris_cursor = (long long)N * P.Ntilde * T;
-        *P.paris_consumed = paris_overflow ? -1ll : paris_cursor;
+        if ((P.flags & PFG_FLAG_PARIS_NO_ACCEPT_REJECT) && !(RAWCAP && raw)) paris_cursor = (long long)N * P.Ntilde * T;
+        P.paris_consumed[0] = paris_overflow ? -1ll : paris_cursor;
+        P.paris_consumed[1] = (RAWCAP && raw && carry_has && !paris_overflow) ? paris_cursor - raw_slots[1] : 0ll;
     }
     if (tid == 0 && P.out) {
 #pragma unroll

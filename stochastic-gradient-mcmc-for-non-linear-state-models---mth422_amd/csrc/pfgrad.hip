@@ -708,8 +708,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                     return fail(ctx, PFG_ERR_INVALID, id + "paris_stream_len and paris_manual_threshold must be >= 0");
                 if (q.N > pfg::MEM_MAX_N)
                     return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'paris' is implemented for N <= 16384");
-                if ((q.flags & PFG_FLAG_PARIS_RAW_STREAM) && q.N > 1024)
-                    return fail(ctx, PFG_ERR_UNSUPPORTED, id + "PFG_FLAG_PARIS_RAW_STREAM is built for N <= 1024 (one launch per timestep above)");
+                if ((q.flags & PFG_FLAG_PARIS_RAW_STREAM) && dtype != PFG_F64)
+                    return fail(ctx, PFG_ERR_UNSUPPORTED, id + "PFG_FLAG_PARIS_RAW_STREAM is built for dtype f64 (it reproduces np.random's doubles)");
                 if ((q.flags & PFG_FLAG_PARIS_RAW_STREAM) && (q.z0 || q.u || q.z))
                     return fail(ctx, PFG_ERR_INVALID, id + "PFG_FLAG_PARIS_RAW_STREAM draws z0 / u / z from paris_stream: they must be NULL");
                 if ((q.flags & PFG_FLAG_PARIS_RAW_CARRY) && (!(q.flags & PFG_FLAG_PARIS_RAW_STREAM) || q.paris_stream_len < 1))
@@ -822,12 +822,6 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "trace_x and trace_logw go together");
         if (r.trace_stats && !r.trace_x) return fail(ctx, PFG_ERR_INVALID, id + "trace_stats needs trace_x");
     }
-    // the kernel is chosen from the batch's largest N: a whole-window PaRIS stream (N <= 1024, no u / z behind it) must not
-    // ride into the large-N kernel with a bigger window of the same batch
-    for (int b = 0; b < B; ++b)
-        if (ps[b].smoother == PFG_SMOOTHER_PARIS && (ps[b].flags & PFG_FLAG_PARIS_RAW_STREAM) && n_max > 1024)
-            return fail(ctx, PFG_ERR_UNSUPPORTED, "problem " + std::to_string(b) + ": PFG_FLAG_PARIS_RAW_STREAM cannot share a batch with a window of N > 1024 (N_max = " +
-                                                  std::to_string(n_max) + "): the large-N kernel takes one launch per timestep");
     bool traced = false;
     for (int b = 0; b < B; ++b)
         traced = traced || rs[b].trace_x || rs[b].trace_ll || rs[b].rec_u || rs[b].rec_z || rs[b].rec_z0 || rs[b].rec_ud || ps[b].elementwise;

@@ -16,6 +16,8 @@ RNG modes
 
 There is no NumPy fallback: without libpfgrad.so and an MI355X every entry point raises.
 """
+import os
+
 import numpy as np
 
 from . import _capi
@@ -269,10 +271,12 @@ def make_problem(model, kernel, pf, observations, theta, N, t1=0, tL=None, weigh
                      t1=int(t1), tL=(T if tL is None else int(tL)), lambduh=1.0, Ntilde=paris_kw["Ntilde"],
                      prior_mean=float(np.asarray(prior_mean).reshape(-1)[0]),
                      prior_var=float(np.asarray(prior_var).reshape(-1)[0]), y=y, weights=weights, theta=theta, flags=flags)
-            if int(N) <= 1024:
-                q["_result"] = _paris_raw_window(q, accept_reject, mar, mst, random_state, ctx=ctx)      # the whole window in one launch
+            # the whole window in one launch (round 4: also 1024 < N <= 16384, the large-N kernel; one launch per timestep
+            # -- _paris_replay_window -- stays available: PFGRAD_PARIS_PER_TIMESTEP=1, A/B and tests)
+            if os.environ.get("PFGRAD_PARIS_PER_TIMESTEP") and int(N) > 1024:
+                q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state, ctx=ctx)
             else:
-                q["_result"] = _paris_replay_window(q, accept_reject, mar, mst, random_state, ctx=ctx)   # one launch per timestep
+                q["_result"] = _paris_raw_window(q, accept_reject, mar, mst, random_state, ctx=ctx)
             return q
         # default rounds: the reference stops accept-reject once <= 10 log10(N/10) children are
         # left and draws those exactly (its own cap is 100 log10(N/10) rounds); a fixed number of
@@ -328,7 +332,7 @@ _RAW_CHUNK = 1 << 16            # the raw stream is drawn in chunks with the gen
 
 
 def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_sample_threshold=None, random_state=None, ctx=None):
-    """One PaRIS window (N <= 1024) consuming the legacy generator EXACTLY as the reference does, in ONE launch
+    """One PaRIS window (N <= 16384) consuming the legacy generator EXACTLY as the reference does, in ONE launch
     (pfgrad.h: PFG_FLAG_PARIS_RAW_STREAM): the host hands the kernel what RandomState.random_sample delivers from the
     generator's current state, the kernel takes from it -- in np.random's order -- the normals of x0 and per timestep N
     uniforms, N normals (NumPy's legacy polar method on pairs of doubles, the second variate of a pair cached) and the
@@ -353,7 +357,8 @@ def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_samp
     key = (N, Nt, bool(accept_reject))
     normals = int(1.36 * N) + 64                     # doubles of one call: N / 2 pairs accepted with probability pi / 4
     per_step = _paris_raw_hint.get(key, 0) * 1.2 or (N + normals + (N * Nt if not accept_reject else 8 * N * Nt))
-    L = int(normals + T * per_step) + 4 * 1024 + 4096     # + the kernel's look-ahead of one round of attempts
+    ahead = 4096 if N <= 1024 else 16384                  # the kernel's look-ahead: one round of attempts (1024 | 4096 pairs of doubles)
+    L = int(normals + T * per_step) + 4 * 1024 + ahead
     while True:
         L = (L + _RAW_CHUNK - 1) // _RAW_CHUNK * _RAW_CHUNK
         stream = np.empty(L + 1)
@@ -399,7 +404,7 @@ def _paris_raw_window(q, accept_reject=True, max_accept_reject=None, manual_samp
         rs.set_state((st[0], st[1], st[2], 0, 0.0))
     stats = o["statistics"][:, :h]
     return dict(mean_stat=np.asarray(o["mean_stat"])[:h], loglik=o["loglik"], x_t=o["x_t"], log_weights=o["log_weights"],
-                statistics=stats, _draws=dict(paris_stream=stream[s0:s0 + used + 4096].copy(), flags=flags, max_accept_reject=mar,
+                statistics=stats, _draws=dict(paris_stream=stream[s0:s0 + used + ahead].copy(), flags=flags, max_accept_reject=mar,
                                               paris_manual_threshold=mst, _consumed=used))     # (+ the kernel's look-ahead)
 
 

@@ -342,6 +342,38 @@ def test_paris_whole_window_in_one_launch(ctx, monkeypatch, model, kernel, N, T,
     assert np.array_equal(a[1], c[1]) and a[2:] == c[2:]
 
 
+def test_paris_large_n_one_launch_equals_one_launch_per_timestep(monkeypatch):
+    """Round 4: 1024 < N <= 16384 runs the whole PaRIS window in ONE launch of the large-N kernel (in-kernel legacy
+    Gaussians, stream cursor carried across timesteps); one launch per timestep (PFGRAD_PARIS_PER_TIMESTEP=1: round 3's
+    path, pinned seed for seed by paris_seed.npz) must give the same numbers and leave np.random at the same place -- with a
+    cached Gaussian pending on entry, accept_reject=False, odd N (a cached variate pending after every call)."""
+    from sgmcmc_ssm_amd import particle_filters as pfm
+    from test_host_logic import default_params, GEN
+    for model, kernel, N, T, kw, pre in (("svm", "prior", 1500, 6, dict(), 0), ("garch", "optimal", 2501, 5, dict(Ntilde=3), 1),
+                                         ("lgssm", "optimal", 1025, 4, dict(accept_reject=False), 0),
+                                         ("svm", "prior", 5000, 3, dict(max_accept_reject=5, manual_sample_threshold=100), 3)):
+        np.random.seed(11)
+        p = default_params(model)
+        y = GEN[model](T=T, parameters=p)["observations"].reshape(-1)
+        outs = []
+        for per_step in (False, True):
+            if per_step:
+                monkeypatch.setenv("PFGRAD_PARIS_PER_TIMESTEP", "1")
+            else:
+                monkeypatch.delenv("PFGRAD_PARIS_PER_TIMESTEP", raising=False)
+            rs = np.random.RandomState(321)
+            for _ in range(pre):
+                rs.normal()                       # an odd number of normals leaves a cached Gaussian behind
+            o = pfm.buffered_pf_wrapper("paris", model, kernel, y, p.theta(), N, random_state=rs, t1=1, tL=T, prior_var=2.0,
+                                        weights=1.0 + np.arange(T - 1), **kw)
+            outs.append((o, rs.get_state()))
+        (a, sa), (b, sb) = outs
+        np.testing.assert_allclose(a["mean_statistic"], b["mean_statistic"], rtol=1e-10, atol=1e-10, err_msg=str((model, N)))
+        np.testing.assert_allclose(a["x_t"], b["x_t"], rtol=1e-10, atol=1e-10)
+        assert abs(a["loglikelihood_estimate"] - b["loglikelihood_estimate"]) <= 1e-10 * abs(b["loglikelihood_estimate"])
+        assert np.array_equal(sa[1], sb[1]) and sa[2:4] == sb[2:4] and abs(sa[4] - sb[4]) <= 1e-12 * max(1.0, abs(sb[4])), (model, N)
+
+
 def test_paris_one_launch_stream_too_short_and_refusals(ctx, monkeypatch):
     """A raw stream that runs out is reported (-1) and the host draws a longer one; the flag's preconditions are checked."""
     from sgmcmc_ssm_amd import _capi, particle_filters as pfm
@@ -369,7 +401,10 @@ def test_paris_one_launch_stream_too_short_and_refusals(ctx, monkeypatch):
     assert ctx.run_batch([dict(base)], want_final=True)[0]["paris_consumed"] == -1
     with pytest.raises(ValueError, match="must be NULL"):
         ctx.run_batch([dict(base, z0=np.zeros(N), u=np.zeros((T, N)), z=np.zeros((T, N)))])
-    with pytest.raises(NotImplementedError, match="N <= 1024"):
-        ctx.run_batch([dict(base, N=2000)])
+    # round 4: the large-N kernel takes the whole-window stream too (f64): a stream that is too short reports -1 there as
+    # well, an f32 window is refused (the stream is np.random's doubles)
+    assert ctx.run_batch([dict(base, N=2000)], want_final=True)[0]["paris_consumed"] == -1
+    with pytest.raises(NotImplementedError, match="dtype f64"):
+        ctx.run_batch([dict(base, N=2000, dtype="f32")])
     with pytest.raises(ValueError, match="RAW_CARRY|replay streams"):          # the binding refuses it before the library does
         ctx.run_batch([dict(base, flags=_capi.FLAG_PARIS_RAW_CARRY)])
