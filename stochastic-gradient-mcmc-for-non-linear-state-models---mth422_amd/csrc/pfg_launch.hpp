@@ -129,7 +129,7 @@ template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_n2(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
     if (n_max <= 256) return launch_n2_one<MODEL, KERNEL, REAL, 256, 1, RNG>(ctx, n_max, B, dp, st);
     if (n_max <= 1024) return launch_n2_one<MODEL, KERNEL, REAL, 256, 4, RNG>(ctx, n_max, B, dp, st);
-    if (n_max <= 4096) {
+    if (n_max <= pfg::MEM_MAX_N) {
         // large-N kernel, PaRIS instantiation (second log-weight array): its O(N^2) sweep (descriptors carry a scratch)
         auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, true>;
         size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
@@ -138,7 +138,7 @@ int launch_n2(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStre
         PFG_HIP(ctx, hipGetLastError());
         return PFG_OK;
     }
-    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2' is implemented for N <= 4096 (N = " + std::to_string(n_max) + ")");
+    return fail(ctx, PFG_ERR_UNSUPPORTED, "pf = 'poyiadjis_N2' is implemented for N <= 16384 (N = " + std::to_string(n_max) + ")");
 }
 
 // systematic-resampling instantiation (extension): device RNG, the fp64 / f32 default 256x4 variants

@@ -691,8 +691,10 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             return fail(ctx, PFG_ERR_INVALID, id + "Unrecognized pf (smoother id)");
         if ((q.smoother == PFG_SMOOTHER_POYIADJIS_N2) != (ps[0].smoother == PFG_SMOOTHER_POYIADJIS_N2))
             return fail(ctx, PFG_ERR_INVALID, id + "pf = 'poyiadjis_N2' cannot share a batch with other smoothers");
-        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.N > 4096)
-            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'poyiadjis_N2' is implemented for N <= 4096");
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.N > pfg::MEM_MAX_N)
+            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "pf = 'poyiadjis_N2' is implemented for N <= 16384");
+        if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.elementwise && q.N > 4096)
+            return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics with pf = 'poyiadjis_N2' are implemented for N <= 4096");
         if (q.smoother == PFG_SMOOTHER_POYIADJIS_N2 && q.stat == PFG_STAT_PREDICTIVE)
             return fail(ctx, PFG_ERR_INVALID, id + "Only can use pf = 'filter' since we are filtering");
         if ((q.smoother == PFG_SMOOTHER_PARIS) != (ps[0].smoother == PFG_SMOOTHER_PARIS))

@@ -57,5 +57,5 @@ def test_counters_belong_to_the_committed_kernel_sources():
     roofline from other sources as stale.  Committed state: not stale."""
     meta = json.load(open(os.path.join(PROF, "profile_meta.json")))
     assert meta["kernel_source_sha"] == bench.kernel_source_sha(), \
-        "kernel sources changed since the last profile run: re-run tools/r03_profiles.sh + tools/make_profiles.py r03"
+        "kernel sources changed since the last profile run: re-run tools/r04_profiles.sh (gpurun) + tools/make_profiles.py r04"
     assert not bench.profile_is_stale()

@@ -102,7 +102,7 @@ def test_n2_device_rng_and_f32(ctx, model, kernel):
     # the O(N^2) estimator has the smaller variance (that is its point)
     assert res[("f64", "poyiadjis_n2")].var(axis=0)[:2].sum() < res[("f64", "nemeth")].var(axis=0)[:2].sum() * 1.5
     with pytest.raises(NotImplementedError):
-        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", N=5000, stream=1)])
+        ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", N=20000, stream=1)])      # above the large-N kernel's 16384
     with pytest.raises(ValueError):
         ctx.run_batch([dict(base, smoother="poyiadjis_n2", dtype="f64", stream=1),
                        dict(base, smoother="nemeth", dtype="f64", stream=2)])
@@ -148,4 +148,29 @@ def test_n2_beyond_lds_device_rng_and_oracle(ctx):
     b = np.array([o["mean_stat"] for o in ctx.run_batch([dict(base, smoother="nemeth", stream=s) for s in range(6)])])
     assert np.all(np.isfinite(a))
     sd = np.sqrt(a.var(axis=0) / 6 + b.var(axis=0) / 6) + 1e-3
+    assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 6 * sd + 0.05 * np.abs(b.mean(axis=0)))
+
+
+def test_n2_up_to_the_large_n_kernels_maximum(ctx):
+    """Round 4: the O(N^2) sweep of the large-N kernel takes any N it can hold (<= 16384; the reference's pf.py:84-136 has
+    no limit, its N x N NumPy arrays do).  N = 6000 against the oracle (REPLAY, per-particle statistics), N = 16384 on the
+    device generator against the O(N) estimate of the same window."""
+    rs = np.random.RandomState(19)
+    theta = np.array([0.95, 0.5 ** -0.5, 0.5 ** -0.5])
+    N, T = 6000, 2
+    y = rs.normal(size=T) * 1.2
+    z0, u, z = po.draw_streams(rs, N, T)
+    ref = po.pf_window("svm", theta, y, N, z0, u, z, kernel="prior", pf="poyiadjis_N2", stat="score", prior_mean=0.0, prior_var=2.0)
+    q = dict(model="svm", kernel="prior", smoother="poyiadjis_n2", stat="score", dtype="f64", rng="replay", N=N, t1=0, tL=T,
+             lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=y, theta=theta, z0=z0, u=u, z=z)
+    o = ctx.run_batch([q], want_final=True)[0]
+    assert ctx.last_variant() == "n2_mem1024"
+    np.testing.assert_allclose(o["statistics"], ref["statistics"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(o["mean_stat"], ref["mean_statistic"], rtol=RTOL, atol=1e-8)
+    base = dict(model="svm", kernel="prior", stat="score", N=16384, t1=0, tL=3, lambduh=1.0, prior_mean=0.0, prior_var=2.0,
+                y=rs.normal(size=3), theta=theta, rng="device", seed=3, dtype="f64")
+    a = np.array([o["mean_stat"] for o in ctx.run_batch([dict(base, smoother="poyiadjis_n2", stream=s) for s in range(4)])])
+    b = np.array([o["mean_stat"] for o in ctx.run_batch([dict(base, smoother="nemeth", stream=s) for s in range(4)])])
+    assert np.all(np.isfinite(a))
+    sd = np.sqrt(a.var(axis=0) / 4 + b.var(axis=0) / 4) + 1e-3
     assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 6 * sd + 0.05 * np.abs(b.mean(axis=0)))
