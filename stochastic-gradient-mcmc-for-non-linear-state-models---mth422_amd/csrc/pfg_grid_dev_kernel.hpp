@@ -36,7 +36,7 @@ __host__ __device__ constexpr size_t grid_dev_lds_doubles(int G) {
            (size_t)((NT / WAVE) * (1 + 2 * PPT + PFG_MAX_STAT + 4 + PFG_MAX_STAT) + 8) + (size_t)(TAB_E2_ACC + 2 * TAB_LG);
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int KMAX>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PPT == 4 ? 4 : 3, PPT == 4 ? 4 : 3)))
 void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) {
     constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT, NW = NT / WAVE;
@@ -81,8 +81,8 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     PFG_GSTAMP(0);
     // ---- prologue, phase 1: every load that depends on nothing is issued first; the arithmetic that depends on nothing
     // (model constants: a few ocml log / exp / divisions; the spacings and their wave scans) runs under their latency ----------
-    constexpr int KMAX = grid_kmax<NT, PPT>();
     const int K = (G + NT - 1) / NT;                                    // tiles per thread in the reduction (<= KMAX)
+    if (K > KMAX) return;                                               // (the host picks KMAX from the batch's largest N)
     double pmq[KMAX], pWq[KMAX], pEq[KMAX];
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) {

@@ -39,30 +39,26 @@
 namespace pfg {
 
 constexpr int GRID_MAX_N = 1 << 22;
-constexpr int GRID_SMALL_N = 1 << 20;          // up to here: 256 threads x 4 children (1024-particle tiles)
-#ifndef PFG_GRID_BIG_NT
-#define PFG_GRID_BIG_NT 512
-#endif
-#ifndef PFG_GRID_BIG_PPT
-#define PFG_GRID_BIG_PPT 4
-#endif
-constexpr int GRID_BIG_NT = PFG_GRID_BIG_NT, GRID_BIG_PPT = PFG_GRID_BIG_PPT;      // above: 2048-particle tiles
-static_assert(GRID_BIG_NT * GRID_BIG_PPT == 2048, "GRID_MAX_N / 2048 tiles is what the tile tables are sized for");
-constexpr int GRID_MAX_TILES = 2048;
+constexpr int GRID_MAX_TILES = 2048;           // GRID_MAX_N / 2048
 constexpr int GRID_COARSE_MAX = 16384;
 constexpr int GRID_HEAD_DOUBLES = 32;
 // head slots
 constexpr int GH_LL = 0, GH_FILT = 1 /* ..4 */, GH_TIE = 5, GH_WALK = 6, GH_M = 7, GH_W = 8, GH_S = 9 /* ..12 */, GH_ERR = 13;
 
-// Tile classes.  Up to 2^19 particles: 256 threads x 4 children = 1024-particle tiles -- a timestep is one short round of
-// workgroups, bound by the length of a workgroup's dependency chain.  Above: 2048-particle tiles, so that the per-tile lists
-// every workgroup reduces (all tiles' partials) and searches are half as long.
-__host__ __device__ inline int grid_nt(int N) { return N <= GRID_SMALL_N ? 256 : GRID_BIG_NT; }
-__host__ __device__ inline int grid_ppt(int N) { return N <= GRID_SMALL_N ? 4 : GRID_BIG_PPT; }
-// tiles per thread in the reduction over the tile partials, at most (loop bounds of the step kernels)
-template <int NT, int PPT> __host__ __device__ constexpr int grid_kmax() {
-    return ((NT * PPT <= 1024 ? GRID_SMALL_N : GRID_MAX_N) / (NT * PPT) + NT - 1) / NT;
-}
+// Tile classes (256 threads per tile; the class is a function of N alone: every kernel of a window must agree on it).
+//   N <= 2^19:          4 children per thread, 1024-particle tiles -- a timestep is one short round of workgroups, bound by
+//                       the length of a workgroup's dependency chain; small tiles = more workgroups to overlap it;
+//   2^19 < N <= 2^22:   8 children per thread, 2048-particle tiles -- the per-tile lists every workgroup reduces (all tiles'
+//                       partials) and searches are half as long, and the per-thread fixed work of a timestep is spread over
+//                       twice the particles (measured, profiles/r04_ab_grid_tile_classes.txt: the reference's ten-window
+//                       computation at N = 10^6 0.41 -> 0.45 of the HBM peak, a lone window unchanged).
+constexpr int GRID_NT = 256;
+constexpr int GRID_SMALL_N = 1 << 19;
+__host__ __device__ inline int grid_nt(int) { return GRID_NT; }
+__host__ __device__ inline int grid_ppt(int N) { return N <= GRID_SMALL_N ? 4 : 8; }
+// tiles per thread in the device-generator step kernel's reduction over the tile partials, at most: its loops are unrolled
+// to this bound, so the N <= 2^20 launches (<= 512 tiles) run an instantiation with 2, larger ones with 8
+__host__ __device__ inline int grid_kmax(int N) { return N <= (1 << 20) ? 2 : 8; }
 
 struct GridLayout {
     int N, NT, PPT, TILE, G, C, S, PSTRIDE;          // C coarse entries of stride S (REPLAY); PSTRIDE doubles per partial parity

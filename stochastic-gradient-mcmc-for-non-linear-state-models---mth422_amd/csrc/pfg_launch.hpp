@@ -179,7 +179,7 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 // phase: PFG_GRID_ALL = init, every timestep, finish; PFG_GRID_INIT / PFG_GRID_FINISH alone; t >= 0: timestep t alone
 // (callers that put events or graph nodes between the launches)
 constexpr int PFG_GRID_ALL = -1, PFG_GRID_INIT = -2, PFG_GRID_FINISH = -3;
-template <int MODEL, int KERNEL, typename REAL, int RNG, int NT, int PPT>
+template <int MODEL, int KERNEL, typename REAL, int RNG, int NT, int PPT, int KMAX>
 int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase) {
     constexpr int NW = NT / pfg::WAVE;
     const pfg::GridLayout L = pfg::grid_layout<MODEL, REAL>(n_max, RNG == PFG_RNG_REPLAY);
@@ -200,7 +200,7 @@ int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_pro
             hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
         }
     } else {
-        auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT>;
+        auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT, KMAX>;
         const size_t lds_step = pfg::grid_dev_lds_doubles<NT, PPT>(L.G) * 8;
         PFG_ENSURE_LDS(ctx, k_step, lds_step);
         for (int t = t_lo; t < t_hi; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
@@ -214,12 +214,15 @@ template <int MODEL, int KERNEL, int RNG>
 int launch_grid_mkr(pfg_ctx *ctx, int dtype, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase) {
     if (n_max > pfg::GRID_MAX_N)
         return fail(ctx, PFG_ERR_UNSUPPORTED, "N = " + std::to_string(n_max) + " exceeds the supported maximum of " + std::to_string(pfg::GRID_MAX_N));
-    const bool big = n_max > pfg::GRID_SMALL_N;
-    if (dtype == PFG_F64)
-        return big ? launch_grid_ppt<MODEL, KERNEL, double, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st, phase)
-                   : launch_grid_ppt<MODEL, KERNEL, double, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st, phase);
-    return big ? launch_grid_ppt<MODEL, KERNEL, float, RNG, pfg::GRID_BIG_NT, pfg::GRID_BIG_PPT>(ctx, n_max, t_max, B, dp, st, phase)
-               : launch_grid_ppt<MODEL, KERNEL, float, RNG, 256, 4>(ctx, n_max, t_max, B, dp, st, phase);
+    const int ppt = pfg::grid_ppt(n_max), kmax = pfg::grid_kmax(n_max);
+    constexpr int NT = pfg::GRID_NT;
+#define PFG_GRID_CASE(REAL_)                                                                                              \
+    (ppt == 4 ? launch_grid_ppt<MODEL, KERNEL, REAL_, RNG, NT, 4, 2>(ctx, n_max, t_max, B, dp, st, phase)               \
+     : kmax == 2 ? launch_grid_ppt<MODEL, KERNEL, REAL_, RNG, NT, 8, 2>(ctx, n_max, t_max, B, dp, st, phase)            \
+                 : launch_grid_ppt<MODEL, KERNEL, REAL_, RNG, NT, 8, 8>(ctx, n_max, t_max, B, dp, st, phase))
+    if (dtype == PFG_F64) return PFG_GRID_CASE(double);
+    return PFG_GRID_CASE(float);
+#undef PFG_GRID_CASE
 }
 
 // every kernel of one (model, proposal kernel, generator): explicitly instantiated in

@@ -225,7 +225,7 @@ int dispatch_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
     if (t_max < 0) return fail(ctx, PFG_ERR_INVALID, "T_max must be >= 0");
     if (B > 65535) return fail(ctx, PFG_ERR_INVALID, "at most 65535 whole-GPU windows per launch");
-    ctx->last_variant = n_max > pfg::GRID_SMALL_N ? "grid2048" : "grid1024";
+    ctx->last_variant = pfg::grid_ppt(n_max) == 8 ? "grid2048" : "grid1024";
     ctx->last_traced = true;
     if (model == PFG_MODEL_SVM) return launch_grid_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
     if (model == PFG_MODEL_GARCH) {
@@ -530,7 +530,7 @@ const char *pfg_variant_name(int model, int kernel, int dtype, int rng, int n_ma
         const char *force = std::getenv("PFGRAD_VARIANT");
         if (!(force && !std::strcmp(force, "mem1024"))) return n_max <= 4096 ? "big4096" : "big16384";
     }
-    if (v == kVariantGrid) return n_max > pfg::GRID_SMALL_N ? "grid2048" : "grid1024";
+    if (v == kVariantGrid) return pfg::grid_ppt(n_max) == 8 ? "grid2048" : "grid1024";
     return v == kVariantMem ? "mem1024" : (v < 0 ? "none" : kVariants[v].tag);
 }
 
@@ -849,8 +849,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
             if (q.smoother != PFG_SMOOTHER_NEMETH && q.smoother != PFG_SMOOTHER_FILTER)
                 return fail(ctx, PFG_ERR_UNSUPPORTED, id + "N > " + std::to_string(pfg::MEM_MAX_N) + " is built for pf = 'poyiadjis_N' | 'nemeth' | 'filter'");
             if (q.elementwise) return fail(ctx, PFG_ERR_UNSUPPORTED, id + "elementwise statistics are built for N <= " + std::to_string(pfg::MEM_MAX_N));
-            if ((q.N > pfg::GRID_SMALL_N) != (n_max > pfg::GRID_SMALL_N))
-                return fail(ctx, PFG_ERR_INVALID, id + "whole-GPU windows of one batch must all have N <= 1048576 or all N > 1048576");
+            if (pfg::grid_ppt(q.N) != pfg::grid_ppt(n_max))
+                return fail(ctx, PFG_ERR_INVALID, id + "whole-GPU windows of one batch must all have N <= 524288 or all N > 524288");
             t_max = q.T > t_max ? q.T : t_max;
         }
     }

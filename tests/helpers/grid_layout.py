@@ -11,8 +11,8 @@ def _al(x):
 def grid_layout(model, dtype, N, replay):
     rs = 8 if dtype == "f64" else 4
     L = {"N": N}
-    L["TILE"] = 1024 if N <= (1 << 20) else 2048
-    L["NT"] = 256 if N <= (1 << 20) else 512           # (256 x 4 | 512 x 4: the default build)
+    L["TILE"] = 1024 if N <= (1 << 19) else 2048       # 256 threads x 4 | 8 children
+    L["NT"] = 256
     L["G"] = (N + L["TILE"] - 1) // L["TILE"]
     S = 64
     while (N + S - 1) // S > 16384:

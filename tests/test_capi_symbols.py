@@ -50,8 +50,8 @@ def test_binding_struct_sizes_and_version():
     assert lib.pfg_variant_name(1, 1, 0, 0, 1000) == b"wg256x4s"      # ... the REPLAY units keep 256 x 4
     assert lib.pfg_variant_name(1, 1, 0, 0, 4000) == b"mem1024" and lib.pfg_variant_name(1, 1, 0, 1, 4000) == b"big4096"
     assert lib.pfg_variant_name(0, 0, 0, 0, 10000) == b"mem1024"
-    # above the one-workgroup kernels' 16384: the whole-GPU window (tiles of 1024 particles up to 2^20, of 2048 above)
-    assert lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"grid1024" and lib.pfg_variant_name(0, 0, 0, 0, 1000000) == b"grid1024" and lib.pfg_variant_name(0, 0, 0, 0, 3000000) == b"grid2048"
+    # above the one-workgroup kernels' 16384: the whole-GPU window (tiles of 1024 particles up to 2^19, of 2048 above)
+    assert lib.pfg_variant_name(0, 0, 0, 1, 20000) == b"grid1024" and lib.pfg_variant_name(0, 0, 0, 0, 500000) == b"grid1024" and lib.pfg_variant_name(0, 0, 0, 0, 1000000) == b"grid2048"
     assert lib.pfg_variant_name(0, 0, 0, 1, (1 << 22) + 1) == b"none"
     assert lib.pfg_scratch_bytes(0, 0, 1, 1000) == 0 and lib.pfg_scratch_bytes(0, 0, 1, (1 << 22) + 1) == -1
     import sys
@@ -60,7 +60,7 @@ def test_binding_struct_sizes_and_version():
     for model, mname in enumerate(("svm", "garch", "lgssm")):
         for dtype, dname in enumerate(("f64", "f32")):
             for rng in (0, 1):
-                for N in (16385, 100000, 1000000, 1 << 20, (1 << 20) + 1, 1 << 22):
+                for N in (16385, 100000, 1 << 19, (1 << 19) + 1, 1000000, (1 << 20) + 1, 1 << 22):
                     assert lib.pfg_scratch_bytes(model, dtype, rng, N) == grid_layout(mname, dname, N, rng == 0)["bytes"]
     assert lib.pfg_scratch_bytes(0, 0, 1, 10000) == (10000 * 9 * 8 + 16 + 255) // 256 * 256
 

@@ -65,7 +65,7 @@ GIANT = [
     ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 131072, 5, "nemeth", 0.95),
     ("garch", "prior", [0.0, 2.0, 2.0, 1.8], 300000, 3, "poyiadjis_N", 1.0),
     ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 262145, 3, "filter", 1.0),
-    ("svm", "prior", [0.9, 1.2, 1.1], 1100003, 3, "poyiadjis_N", 1.0),            # 2048-particle tiles (N > 2^20)
+    ("svm", "prior", [0.9, 1.2, 1.1], 1100003, 3, "poyiadjis_N", 1.0),            # 2048-particle tiles (N > 2^19)
     ("svm", "prior", [0.9, 1.2, 1.1], 50000, 6, "filter", 1.0),
 ]
 
@@ -82,7 +82,7 @@ def test_giant_replay_ancestors_are_the_references(ctx, case):
     q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="replay", N=N,
              t1=t1, tL=tL, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w, theta=theta, z0=z0, u=u, z=z)
     o = ctx.run_batch([q], want_final=True, want_trace=True)[0]
-    assert ctx.last_variant() == ("grid2048" if N > (1 << 20) else "grid1024")
+    assert ctx.last_variant() == ("grid2048" if N > (1 << 19) else "grid1024")
     r = po.pf_window(model, theta, y, N, z0, u, z, kernel=kernel, pf=pf, lambduh=lam, t1=t1, tL=tL, weights=w,
                      prior_mean=0.0, prior_var=1.5, save_all=True)
     flips = int(np.sum(o["all_ancestors"] != r["all_ancestors"]))
@@ -246,7 +246,7 @@ DEVICE_CASES = [
     ("garch", "optimal", [0.0, 2.0, 2.0, 1.8], 50001, 5, "nemeth", 0.9),
     ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 100000, 4, "filter", 1.0),
     ("svm", "prior", [0.9, 1.2, 1.1], 300000, 4, "poyiadjis_N", 1.0),
-    ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 1200000, 3, "nemeth", 0.9),          # 2048-particle tiles (N > 2^20)
+    ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 1200000, 3, "nemeth", 0.9),          # 2048-particle tiles (N > 2^19)
 ]
 
 
@@ -261,7 +261,7 @@ def test_giant_device_launch_replayed_by_oracle(ctx, case):
     q = dict(model=model, kernel=kernel, smoother=smoother, stat="score", dtype="f64", rng="device", N=N,
              t1=t1, tL=tL, lambduh=lam, prior_mean=0.0, prior_var=1.5, y=y, weights=w, theta=theta, seed=1234 + N, stream=7)
     o = ctx.run_batch([q], want_final=True, want_trace=True, want_draws=True)[0]
-    TILE = 2048 if N > (1 << 20) else 1024
+    TILE = 2048 if N > (1 << 19) else 1024
     ud = o["rec_ud"]
     assert np.all(np.diff(ud, axis=1) >= 0) and ud.min() > 0 and ud.max() < 1          # sorted uniforms, rank order
     flips = [0]
@@ -322,7 +322,7 @@ def test_million_particles_kalman_ground_truth_and_resampling_counts(ctx):
     for s in range(4):
         q["stream"] = s
         outs.append(ctx.run_batch([dict(q)])[0])
-    assert ctx.last_variant() == "grid1024"
+    assert ctx.last_variant() == "grid2048"
     g = np.array([o["mean_stat"] for o in outs])
     ll = np.array([o["loglik"] for o in outs])
     # small-N runs of the one-workgroup kernels on the same data: their mean converges to the same place like 1/N
