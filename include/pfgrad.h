@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 123          /* 0.1.23 */
+#define PFG_VERSION 124          /* 0.1.24 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -63,7 +63,15 @@ enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTH
                     /* poyiadjis_smoother, the O(N^2) algorithm (pf.py:84-136): every child averages
                      * stats_j + w_t h(x_j, child) over ALL parents j with the backward weights
                      * w_j q(child | x_j), normalised per child.  N <= 1024. */
-                    PFG_SMOOTHER_POYIADJIS_N2 = 4 };
+                    PFG_SMOOTHER_POYIADJIS_N2 = 4,
+                    /* LAUNCH-LEVEL id only (pfg_launch_device_smoother; never in a descriptor): the caller states that
+                     * every descriptor of the batch is the Poyiadjis O(N) score -- smoother = NEMETH, lambduh = 1.0,
+                     * stat = SCORE (what pf = 'poyiadjis_N' means, pf.py:139-180).  Same kernels and the same numbers
+                     * as NEMETH; the 1024 x 4 fp64 device-generator unit (1024 < N <= 4096) runs a twin with the filter,
+                     * the lambda != 1 shrinkage and the other statistics compiled out (BASELINE config 4: -4.7 %).
+                     * A descriptor that breaks the statement gets out[0..7] = NaN from that twin.  pfg_run_batch
+                     * chooses it by itself when every window of the batch qualifies. */
+                    PFG_SMOOTHER_POYIADJIS_N = 5 };
 /* additive statistic: *_complete_data_loglike_gradient (score), *_sufficient_statistics, zero */
 enum pfg_stat { PFG_STAT_SCORE = 0, PFG_STAT_SUFF = 1, PFG_STAT_NONE = 2,
                 /* k-step-ahead predictive log-likelihoods accumulated with the filter's

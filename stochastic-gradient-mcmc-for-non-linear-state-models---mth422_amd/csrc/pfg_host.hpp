@@ -64,6 +64,7 @@ struct pfg_ctx {
     std::vector<pfg_dev_problem> h_desc;
     const char *last_variant = "none";   // tag of the kernel variant the latest dispatch launched
     bool last_traced = false;            // ... and whether that was a trace-honouring instantiation
+    bool score1 = false;                 // the dispatch in flight is a PFG_SMOOTHER_POYIADJIS_N launch (see launch_one)
     // largest dynamic-LDS size hipFuncAttributeMaxDynamicSharedMemorySize has been set to, per kernel: the
     // attribute is per (function, device) and a context is bound to one device
     std::unordered_map<const void *, size_t> lds_set;

@@ -23,17 +23,26 @@ namespace pfg_host {
 
 // traced = the descriptors may carry trace_* / rec_* buffers: the TRACE = true instantiation; otherwise the twin with
 // the trace instrumentation compiled out (device generator: what bench.py times; REPLAY: the drop-in Sampler's launch).
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool TRACE>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, bool TRACE, bool SCORE1 = false>
 int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st) {
-    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, pfg::MODE_PLAIN, TRACE>;
+    auto kern = pfg::pf_reg_kernel<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, pfg::MODE_PLAIN, TRACE, SCORE1>;
     size_t lds = pfg::reg_kernel_lds_bytes<MODEL, REAL, NT, PPT, RNG, PP>(n_max);
     PFG_ENSURE_LDS(ctx, kern, lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, st, dp);
     PFG_HIP(ctx, hipGetLastError());
     return PFG_OK;
 }
+// ctx->score1: the caller launched with PFG_SMOOTHER_POYIADJIS_N (every descriptor: NEMETH, lambduh = 1, score) -- the
+// 1024 x 4 fp64 device unit has a twin specialised to that (see SCORE1 in pfg_reg_kernel.hpp); every other unit runs
+// its general kernel
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
+    if constexpr (NT == 1024 && PPT == 4 && RNG == PFG_RNG_DEVICE && !PP && sizeof(REAL) == 8) {
+        if (!traced && ctx->score1) {
+            ctx->last_variant = "wg1024x4s_score1";
+            return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false, true>(ctx, n_max, B, dp, st);
+        }
+    }
     if (!traced) return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false>(ctx, n_max, B, dp, st);
     return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, true>(ctx, n_max, B, dp, st);
 }

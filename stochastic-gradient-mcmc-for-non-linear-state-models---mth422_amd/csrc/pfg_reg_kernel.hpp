@@ -171,7 +171,7 @@ __host__ __device__ constexpr bool occ_dev4(int MODEL, int NT, int PPT, int RNG,
     return PFG_OCC4 && MODEL == PFG_MODEL_SVM && NT == 256 && PPT == 4 && !PP && RNG == PFG_RNG_DEVICE && MODE == MODE_PLAIN;
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0, bool TRACE = true>
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP, int MODE = 0, bool TRACE = true, bool SCORE1 = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_min(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE)), occ_two(MODEL, NT, PPT, sizeof(REAL), PP) ? 2 : occ_max(NT, PPT, sizeof(REAL), PP, occ_dev4(MODEL, NT, PPT, RNG, PP, MODE))))) void pf_reg_kernel(const pfg_dev_problem *__restrict__ probs) {
     constexpr bool PARIS = (MODE == MODE_PARIS);
     constexpr bool systematic = (MODE == MODE_SYSTEMATIC);
@@ -188,9 +188,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(occ_two(MODE
     const int NL = fast_layout(NT, PP) ? NT * PPT : (N + WAVE - 1) / WAVE * WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-    const bool is_filter = !PFG_EXP_PLAIN && (P.smoother == PFG_SMOOTHER_FILTER);
-    const int stat = PFG_EXP_PLAIN ? (int)PFG_STAT_SCORE : P.stat;
-    const double lam_d = PFG_EXP_PLAIN ? 1.0 : is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
+    // SCORE1 (PFG_SMOOTHER_POYIADJIS_N launches of the 1024 x 4 unit): the Poyiadjis O(N) score only -- the filter, the
+    // lambda != 1 shrinkage and the other statistics compiled out (config 4: 10.56 -> 10.07 ms, no spilled VGPR; the
+    // 256 x 4 unit gains 0.5 %, the 512 x 2 one loses 2 %: profiles/r04_ab_score1_twin.txt).  A descriptor that is not
+    // (NEMETH, lambduh = 1, SCORE) gets NaNs, loudly, instead of another estimator's numbers.
+    constexpr bool ONLY_SCORE1 = PFG_EXP_PLAIN || SCORE1;
+    if constexpr (SCORE1) {
+        if (P.smoother != PFG_SMOOTHER_NEMETH || P.lambduh != 1.0 || P.stat != PFG_STAT_SCORE) {
+            if (threadIdx.x < PFG_OUT_DOUBLES && P.out) P.out[threadIdx.x] = __builtin_nan("");
+            return;
+        }
+    }
+    const bool is_filter = !ONLY_SCORE1 && (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = ONLY_SCORE1 ? (int)PFG_STAT_SCORE : P.stat;
+    const double lam_d = ONLY_SCORE1 ? 1.0 : is_filter ? 0.0 : ((P.smoother == PFG_SMOOTHER_PARIS || N2) ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const gptr<const double> yv = global_ptr(P.y);

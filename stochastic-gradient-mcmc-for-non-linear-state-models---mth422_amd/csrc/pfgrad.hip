@@ -178,6 +178,14 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
+    // PFG_SMOOTHER_POYIADJIS_N: the caller states that every descriptor is (NEMETH, lambduh = 1, score) -- same kernels as
+    // NEMETH, except where a unit has a twin specialised to that estimator (launch_one)
+    ctx->score1 = (smoother == PFG_SMOOTHER_POYIADJIS_N) && !traced;
+    if (ctx->score1) {
+        const char *off = std::getenv("PFGRAD_NO_SCORE1");      // A/B timing: the general kernel for these launches too
+        if (off && off[0] == '1') ctx->score1 = false;
+    }
+    if (smoother == PFG_SMOOTHER_POYIADJIS_N) smoother = PFG_SMOOTHER_NEMETH;
     int v = smoother == PFG_SMOOTHER_PARIS ? kVariantParis
             : smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC ? kVariantSystematic
             : smoother == PFG_SMOOTHER_POYIADJIS_N2 ? kVariantN2
@@ -546,7 +554,7 @@ int pfg_launch_device_traced(pfg_ctx *ctx, int model, int kernel, int dtype, int
                              const pfg_dev_problem *dev_probs, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_traced: dev_probs is NULL");
-    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N2)
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N)
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother, false, true);
@@ -556,7 +564,7 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
                                int B, const pfg_dev_problem *dev_probs, void *hip_stream) {
     if (!ctx) return PFG_ERR_INVALID;
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_smoother: dev_probs is NULL");
-    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N2)
+    if (smoother < PFG_SMOOTHER_NEMETH || smoother > PFG_SMOOTHER_POYIADJIS_N)
         return fail(ctx, PFG_ERR_INVALID, "Unrecognized pf (smoother id)");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch(ctx, model, kernel, dtype, rng, n_max, B, dev_probs, (hipStream_t)hip_stream, smoother, false, false);
@@ -827,6 +835,9 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     bool traced = false;
     for (int b = 0; b < B; ++b)
         traced = traced || rs[b].trace_x || rs[b].trace_ll || rs[b].rec_u || rs[b].rec_z || rs[b].rec_z0 || rs[b].rec_ud || ps[b].elementwise;
+    bool score1 = !traced;          // every window the Poyiadjis O(N) score: units with a twin specialised to it run that
+    for (int b = 0; b < B; ++b)
+        score1 = score1 && ps[b].smoother == PFG_SMOOTHER_NEMETH && ps[b].lambduh == 1.0 && ps[b].stat == PFG_STAT_SCORE;
     const bool paris = ps[0].smoother == PFG_SMOOTHER_PARIS;
     const bool sysres = ps[0].smoother == PFG_SMOOTHER_NEMETH_SYSTEMATIC;
     const bool predictive = ps[0].stat == PFG_STAT_PREDICTIVE;   // large-N kernel only (any N)
@@ -1036,7 +1047,7 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
     else
         rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
                       ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC
-                                   : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : PFG_SMOOTHER_NEMETH,
+                                   : n2 ? PFG_SMOOTHER_POYIADJIS_N2 : score1 ? PFG_SMOOTHER_POYIADJIS_N : PFG_SMOOTHER_NEMETH,
                       predictive, traced);
     if (rc) return rc;
     for (int b = 0; b < B; ++b) {

@@ -14,7 +14,8 @@ from . import _build
 # ---- enums (include/pfgrad.h) ---------------------------------------------------------
 MODEL = {"svm": 0, "garch": 1, "lgssm": 2}
 KERNEL = {"prior": 0, "optimal": 1}
-SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2, "nemeth_systematic": 3, "poyiadjis_n2": 4}
+SMOOTHER = {"nemeth": 0, "filter": 1, "paris": 2, "nemeth_systematic": 3, "poyiadjis_n2": 4,
+            "poyiadjis_n": 5}       # launch-level id only (never in a descriptor): see include/pfgrad.h
 STAT = {"score": 0, "suff": 1, "none": 2, "predictive": 3}
 DTYPE = {"f64": 0, "f32": 1}
 RNG = {"replay": 0, "device": 1, "philox": 1}     # "philox" = alias of "device" (Philox-keyed lanes)

@@ -318,6 +318,10 @@ class ChainEnsemble(object):
         elif self.resampling == "systematic":
             self.ctx.launch_device_smoother(self.model, self.kernel, self.dtype, "device", "nemeth_systematic",
                                             self.N, self.C, self.desc_dev.data_ptr(), st)
+        elif self.lambduh == 1.0:
+            # every chain the Poyiadjis O(N) score (NEMETH, lambduh = 1, score): units with a twin specialised to it run that
+            self.ctx.launch_device_smoother(self.model, self.kernel, self.dtype, "device", "poyiadjis_n",
+                                            self.N, self.C, self.desc_dev.data_ptr(), st)
         else:
             self.ctx.launch_device(self.model, self.kernel, self.dtype, "device", self.N, self.C,
                                    self.desc_dev.data_ptr(), st)

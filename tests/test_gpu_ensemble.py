@@ -407,3 +407,40 @@ def test_device_generator_large_sample():
     for k in ("chi2_normal_equiprobable", "chi2_words_top12", "chi2_words_low8"):
         assert o[k]["p"] > 1e-5, (k, o[k])
     assert abs(o["corr_neighbouring_chains"]["z"]) < 5 and abs(o["corr_word_normal"]["z"]) < 5
+
+
+def test_poyiadjis_n_twin_of_the_1024_thread_unit():
+    """PFG_SMOOTHER_POYIADJIS_N launches (what ChainEnsemble issues for lambduh = 1) run the 1024 x 4 fp64 unit's twin with
+    the filter / lambda != 1 / other statistics compiled out: bitwise the numbers of the general kernel (same key, same
+    draws), and a descriptor that is not (NEMETH, lambduh = 1, score) gets NaNs from it, not another estimator's result."""
+    import torch
+    from sgmcmc_ssm_amd.ensemble import ChainEnsemble
+    from sgmcmc_ssm_amd import _capi
+    y = _series("svm", 40)
+    p = default_params("svm")
+    ens = ChainEnsemble("svm", y, p, num_chains=6, N=4000, epsilon=1e-3, seed=21)
+    st = torch.cuda.current_stream().cuda_stream
+    ens.launch_pf()                                       # lambduh = 1: the POYIADJIS_N launch
+    ens.synchronize()
+    assert ens.ctx.last_variant() == "wg1024x4s_score1"
+    twin = ens.out_dev.cpu().numpy().copy()
+    ens.out_dev.zero_()
+    ens.ctx.launch_device(ens.model, ens.kernel, ens.dtype, "device", ens.N, ens.C, ens.desc_dev.data_ptr(), st)
+    ens.synchronize()
+    assert ens.ctx.last_variant() == "wg1024x4s"
+    general = ens.out_dev.cpu().numpy().copy()
+    assert np.isfinite(general[:, :5]).all() and np.array_equal(twin, general)
+    # chain 2 asks for lambduh = 0.9, chain 4 for the filter: the twin refuses them, the others are untouched
+    d = ens._desc.copy()
+    d["lambduh"][2] = 0.9
+    d["smoother"][4] = _capi.SMOOTHER["filter"]
+    bad = torch.from_numpy(d.view(np.uint8).reshape(ens.C, -1).copy()).to(ens.device)
+    ens.out_dev.zero_()
+    ens.ctx.launch_device_smoother(ens.model, ens.kernel, ens.dtype, "device", "poyiadjis_n", ens.N, ens.C, bad.data_ptr(), st)
+    ens.synchronize()
+    o = ens.out_dev.cpu().numpy()
+    assert np.isnan(o[[2, 4]]).all() and np.array_equal(o[[0, 1, 3, 5]], general[[0, 1, 3, 5]])
+    # the general kernel serves them
+    ens.ctx.launch_device(ens.model, ens.kernel, ens.dtype, "device", ens.N, ens.C, bad.data_ptr(), st)
+    ens.synchronize()
+    assert np.isfinite(ens.out_dev.cpu().numpy()[:, :5]).all()

@@ -157,7 +157,7 @@ def weights(blocks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--unit", default="svm_prior_device")
-    ap.add_argument("--kernel", default="pf_reg_kernel<0, 0, double, 256, 4, 1, false, 0, false>")
+    ap.add_argument("--kernel", default="pf_reg_kernel<0, 0, double, 256, 4, 1, false, 0, false, false>")
     ap.add_argument("--ppt", type=int, default=4)
     ap.add_argument("--flags", default="", help="extra compiler flags, space separated in ONE argument")
     ap.add_argument("--write", default=None)
