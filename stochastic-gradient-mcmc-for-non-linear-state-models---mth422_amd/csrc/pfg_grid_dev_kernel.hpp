@@ -111,14 +111,14 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     // model constants: derived once per window by the init kernel (ocml log / exp / divisions: ~600 instructions that
     // every workgroup of every timestep would repeat), here a handful of scalar loads
     const Consts<REAL> c = *reinterpret_cast<const Consts<REAL> *>(base + L.consts);
-    double incE[PPT];
+    float incE[PPT];                                                    // in-wave running sums of the spacings: f32 values
     bool v[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         v[k] = b * TILE + k * NT + tid < N;
         const float ef = spacing_f32(rng.next());
-        incE[k] = (double)wave_incl_scan_f32(v[k] ? ef : 0.0f);         // the instructions of grid_dev_epilogue: same bits
-        if (lane == WAVE - 1) redSE[k * NW + wave] = incE[k];
+        incE[k] = wave_incl_scan_f32(v[k] ? ef : 0.0f);                 // the instructions of grid_dev_epilogue: same bits
+        if (lane == WAVE - 1) redSE[k * NW + wave] = (double)incE[k];
     }
     (void)rng.next();                                                   // the (N+1)-th spacing's word (in the total already)
     double mloc = -INFINITY;
@@ -161,20 +161,6 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
         for (int h = 0; h < H; ++h) {
             const double sh = wave_sum(sl[h]);
             if (lane == WAVE - 1) redV[wave * (3 + H) + 3 + h] = sh;
-        }
-    }
-    // offsets of this thread's children among the tile's spacings (wave totals of phase 1)
-    double offE[PPT];
-    {
-        double run = 0.0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            offE[k] = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                offE[k] = w == wave ? run : offE[k];
-                run += redSE[k * NW + w];
-            }
         }
     }
     __syncthreads();                                                            // barrier P2
@@ -247,10 +233,20 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
         tlo = __builtin_amdgcn_readfirstlane(lo0);
         thi = __builtin_amdgcn_readfirstlane(lo1);
     }
+    {
+        // offsets of this thread's children among the tile's spacings (wave totals of phase 1), then the uniforms
+        double run = 0.0;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        u[k] = (PE_own + offE[k] + incE[k]) * invEtot;
-        pt[k] = tlo;
+        for (int k = 0; k < PPT; ++k) {
+            double offE = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                offE = w == wave ? run : offE;
+                run += redSE[k * NW + w];
+            }
+            u[k] = (PE_own + offE + (double)incE[k]) * invEtot;
+            pt[k] = tlo;
+        }
     }
     for (int j = tlo; j < thi; ++j) {                          // usually one or two iterations
         const double e = pwn[j];
@@ -261,20 +257,15 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     for (int k = 0; k < PPT; ++k) {
         const int i = b * TILE + k * NT + tid;
         pt[k] = v[k] ? pt[k] : -1;
-        if (v[k]) {
-            atomicOr(&bitmap[pt[k] >> 6], 1ull << (pt[k] & 63));
-            if (P.trace_x && P.rec_ud) P.rec_ud[(size_t)t * N + i] = u[k];
-        }
+        if (v[k] && P.trace_x && P.rec_ud) P.rec_ud[(size_t)t * N + i] = u[k];
     }
-    REAL zk[PPT];
+    // the tiles somebody descends from: one LDS atomic per wave and candidate tile (the candidates are the handful of
+    // tiles tlo .. thi; 2048 same-address atomics, one per child, serialised in the LDS)
+    for (int j = tlo; j <= thi; ++j) {
+        bool hit = false;
 #pragma unroll
-    for (int k = 0; k < PPT; k += 2) mth.normal_pair(rng.next(), rng.next(), zk[k], zk[k + 1]);
-    if (P.trace_x && P.rec_z) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = b * TILE + k * NT + tid;
-            if (v[k]) P.rec_z[(size_t)t * N + i] = (double)zk[k];
-        }
+        for (int k = 0; k < PPT; ++k) hit = hit || pt[k] == j;
+        if (__ballot(hit) != 0ull && lane == 0) atomicOr(&bitmap[j >> 6], 1ull << (j & 63));
     }
     __syncthreads();                                                            // barrier P4: bitmap complete
     PFG_GSTAMP(4);
@@ -344,6 +335,18 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
             alignas(16) REAL r[4][REC];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) rec_load<REC, REAL>(r[kk], recc + (size_t)anc[k0 + kk] * REC);
+            // this batch's standard normals, under the latency of its gathers (generator order: the spacings, then the
+            // PPT normals in child order)
+            REAL zb[4];
+            mth.normal_pair(rng.next(), rng.next(), zb[0], zb[1]);
+            mth.normal_pair(rng.next(), rng.next(), zb[2], zb[3]);
+            if (P.trace_x && P.rec_z) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int i = b * TILE + (k0 + kk) * NT + tid;
+                    if (v[k0 + kk]) P.rec_z[(size_t)t * N + i] = (double)zb[kk];
+                }
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = k0 + kk;
@@ -353,7 +356,7 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
                 for (int d = 0; d < NS; ++d) xp[d] = r[kk][d];
 #pragma unroll
                 for (int h = 0; h < H; ++h) sp[h] = r[kk][NS + h];
-                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zk[k], xn, lwv, add);
+                particle_step<MODEL, KERNEL, STAT, REAL>(c, mth, xp, (REAL)y_t, zb[kk], xn, lwv, add);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     const REAL av = use_stat ? add[h] * (REAL)wt : (REAL)0;
