@@ -60,8 +60,7 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     double *pwn = reinterpret_cast<double *>(smem);                      // [G]: where tile j's CDF ends (inclusive prefix of the scaled tile weights / W)
     double *scn = pwn + ((G + 2) & ~1);                                  // [G]: exp(m_j - m) / W, what turns tile j's local scan into CDF increments
     double *cdfl = scn + ((G + 2) & ~1);                                 // [2][TILE]
-    unsigned long long *bitmap = reinterpret_cast<unsigned long long *>(cdfl + 2 * TILE);     // [G / 64 + 1]
-    double *red = reinterpret_cast<double *>(bitmap + (G / 64 + 2));
+    double *red = cdfl + 2 * TILE + (G / 64 + 2);
     double *redM = red, *redSE = redM + NW;                              // prologue: [NW] maxima | [PPT NW] spacing wave totals
     double *redV = redSE + PPT * NW;                                     // [NW][3 + H]: v, e, e_own, S_h wave totals
     double *tabmem = red + (NW * (1 + 2 * PPT + PFG_MAX_STAT + 4 + PFG_MAX_STAT) + 8);
@@ -101,7 +100,7 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     {
         gptr<const double> tabg = global_ptr(reinterpret_cast<const double *>(base + L.tab));
         for (int q = tid; q < TAB_E2 + 2 * TAB_LG; q += NT) tabmem[q] = tabg[q];
-        for (int q = tid; q < G / 64 + 1; q += NT) bitmap[q] = 0ull;
+        if (PPT == 8) { for (int q = tid; q < G / 64 + 1; q += NT) reinterpret_cast<unsigned long long *>(cdfl + 2 * TILE)[q] = 0ull; }
     }
     const double y_t = yv[t];
     const bool inside = (t >= t1) && (t < tL);
@@ -222,13 +221,13 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     int tlo, thi;
     {
         const double ulo = PE_own * invEtot, uhi = (PE_own + e_own_tile) * invEtot;
+        // count of tiles j <= G - 2 with pwn[j] <= bound (at most G - 1): pwn is non-decreasing, so the count is the sum of the
+        // lanes' hits -- G / 64 independent LDS reads and ballots per wave instead of log2 G dependent round trips
         int lo0 = 0, lo1 = 0;
-        int gp = 1;
-        while (gp < G) gp <<= 1;
-        for (int step = gp >> 1; step >= 1; step >>= 1) {       // count of tiles j <= G - 2 with pwn[j] <= bound (at most G - 1)
-            const int q0 = lo0 + step - 1, q1 = lo1 + step - 1;
-            lo0 += (q0 < G - 1 && pwn[q0] <= ulo) ? step : 0;
-            lo1 += (q1 < G - 1 && pwn[q1] <= uhi) ? step : 0;
+        for (int q = lane; q < ((G - 1 + WAVE - 1) & ~(WAVE - 1)); q += WAVE) {
+            const double e = q < G - 1 ? pwn[q] : 2.0;
+            lo0 += __popcll(__ballot(e <= ulo));
+            lo1 += __popcll(__ballot(e <= uhi));
         }
         tlo = __builtin_amdgcn_readfirstlane(lo0);
         thi = __builtin_amdgcn_readfirstlane(lo1);
@@ -259,39 +258,58 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
         pt[k] = v[k] ? pt[k] : -1;
         if (v[k] && P.trace_x && P.rec_ud) P.rec_ud[(size_t)t * N + i] = u[k];
     }
-    // the tiles somebody descends from: one LDS atomic per wave and candidate tile (the candidates are the handful of
-    // tiles tlo .. thi; 2048 same-address atomics, one per child, serialised in the LDS)
-    for (int j = tlo; j <= thi; ++j) {
-        bool hit = false;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) hit = hit || pt[k] == j;
-        if (__ballot(hit) != 0ull && lane == 0) atomicOr(&bitmap[j >> 6], 1ull << (j & 63));
-    }
-    __syncthreads();                                                            // barrier P4: bitmap complete
     PFG_GSTAMP(4);
 
     // ---- the parent tiles this tile's children descend from, in order: search only ------------------------------------------
-    // next set bit of the bitmap at or after `from` (uniform; G if none)
+    // Every parent tile lies in tlo .. thi and -- the uniforms being N + 1 spacings' running sums -- a tile of that range
+    // without a child is a tile of (next to) no weight.  Two ways to walk them, chosen per tile class by measurement on one
+    // box (profiles/r04_ab_grid_tile_classes.txt):
+    //   256 x 4: walk the whole range (an interior tile of exactly zero weight is stepped over) -- no per-child bookkeeping,
+    //            no barrier, the first pass starts as soon as tlo is known (N = 4 10^5, 4 windows: 37.2 -> 36.0 us per step);
+    //   256 x 8: a bitmap of the tiles somebody descends from (one LDS atomic per wave and candidate tile) and a barrier,
+    //            then only the marked tiles (g1, N = 10^6: 1052 windows/s against 1008 with the walk).
+#ifndef PFG_GRID_BITMAP
+#define PFG_GRID_BITMAP (PPT == 8)
+#endif
+    constexpr bool BITMAP = PFG_GRID_BITMAP;
+    unsigned long long *bitmap = reinterpret_cast<unsigned long long *>(cdfl + 2 * TILE);     // [G / 64 + 1]
+    if constexpr (BITMAP) {
+        for (int j = tlo; j <= thi; ++j) {
+            bool hit = false;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) hit = hit || pt[k] == j;
+            if (__ballot(hit) != 0ull && lane == 0) atomicOr(&bitmap[j >> 6], 1ull << (j & 63));
+        }
+        __syncthreads();                                                        // barrier P4: bitmap complete
+    }
     auto next_tile = [&](int from) {
-        int w = from >> 6;
-        const int nwords = G / 64 + 1;
-        unsigned long long bits = w < nwords ? bitmap[w] & (~0ull << (from & 63)) : 0ull;
-        while (bits == 0ull && ++w < nwords) bits = bitmap[w];
-        const int r = bits ? w * 64 + __builtin_ctzll(bits) : G;
-        return __builtin_amdgcn_readfirstlane(r);
+        if constexpr (BITMAP) {
+            int w = from >> 6;
+            const int nwords = G / 64 + 1;
+            unsigned long long bits = w < nwords ? bitmap[w] & (~0ull << (from & 63)) : 0ull;
+            while (bits == 0ull && ++w < nwords) bits = bitmap[w];
+            const int r = bits ? w * 64 + __builtin_ctzll(bits) : G;
+            return __builtin_amdgcn_readfirstlane(r);
+        } else {
+            int j = from;
+            while (j < thi && !(pwn[j] > (j > 0 ? pwn[j - 1] : 0.0))) ++j;
+            return __builtin_amdgcn_readfirstlane(j <= thi ? j : G);
+        }
     };
     // Two parent tiles per pass (a child tile usually descends from one or two): both scans are loaded together, turned
     // into CDF segments side by side in LDS, and every child searches its own parent tile's half -- once.
     int anc[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) anc[k] = 0;
-    int pA = next_tile(0);
+    int pA = next_tile(tlo);
     PFG_GSTAMP(5);
     while (pA < G) {
         const int pB = next_tile(pA + 1);
         const int nvA = (N - pA * TILE) < TILE ? (N - pA * TILE) : TILE;
         const int nvB = pB < G ? ((N - pB * TILE) < TILE ? (N - pB * TILE) : TILE) : 0;
         double cA[PPT], cB[PPT];
+        // (requesting the scans of tiles tlo, tlo + 1 ahead of barrier P4 -- they usually are pA, pB -- was measured: the 16
+        // doubles held across the barrier cost more than the latency they hide, g1 1053 -> 1020 windows/s)
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             cA[k] = (k * NT + tid < nvA) ? csc[(size_t)pA * TILE + k * NT + tid] : 0.0;
@@ -306,19 +324,24 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
             cdfl[TILE + k * NT + tid] = (k * NT + tid < nvB) ? fma(cB[k], scB, pwB) : 2.0;
         }
         __syncthreads();
-        int pos[PPT], half[PPT];
+        // the search variable is the LDS byte address (the probe offsets fold into the ds_read immediates); a child of the
+        // second tile starts TILE entries in
+        using lds_f64 = const __attribute__((address_space(3))) double;
+        const uint32_t cdf_base = (uint32_t)(uintptr_t)(lds_f64 *)cdfl;
+        uint32_t pos[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { pos[k] = 0; half[k] = pt[k] == pB ? TILE : 0; }
+        for (int k = 0; k < PPT; ++k) pos[k] = cdf_base + (pt[k] == pB ? 8u * TILE : 0u);
 #pragma unroll
         for (int step = TILE >> 1; step >= 1; step >>= 1) {
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) pos[k] += (cdfl[half[k] + pos[k] + step - 1] <= u[k]) ? step : 0;
+            for (int k = 0; k < PPT; ++k) pos[k] += (*(lds_f64 *)(uintptr_t)(pos[k] + 8u * (step - 1)) <= u[k]) ? 8u * step : 0u;
         }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const bool inB = pt[k] == pB;
             const int nv = inB ? nvB : nvA;
-            const int pp = pos[k] < nv - 1 ? pos[k] : nv - 1;
+            const int pl = (int)((pos[k] - cdf_base) >> 3) - (inB ? TILE : 0);
+            const int pp = pl < nv - 1 ? pl : nv - 1;
             anc[k] = (pt[k] == pA || (inB && pB < G)) ? (inB ? pB : pA) * TILE + pp : anc[k];
         }
         pA = pB < G ? next_tile(pB + 1) : G;

@@ -3,7 +3,7 @@ cd /root/repo
 L=/root/repo/stochastic-gradient-mcmc-for-non-linear-state-models---mth422_amd/csrc
 for lib in libpfgrad.so libpfgrad_$1.so; do
   echo "== $lib"
-  PFGRAD_LIB=$L/$lib GRID_TIME_REPLAY=0 GRID_TIME_MODELS=svm timeout -k 10 200 python tools/grid_time.py 600000 1000000 2>/dev/null | python -c "
+  PFGRAD_LIB=$L/$lib GRID_TIME_REPLAY=0 GRID_TIME_MODELS=svm timeout -k 10 200 python tools/grid_time.py ${GRID_AB_NS:-600000 1000000} 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     try: r=json.loads(l)
