@@ -1,21 +1,24 @@
 // libpfgrad device code: the timestep of the whole-GPU window with the DEVICE generator -- the throughput path.
 // (Overview of the whole-GPU window: pfg_grid_kernel.hpp.)
 //
-// One launch = one timestep of every window of the batch; one workgroup = one tile of TILE = NT * 4 children.  A
+// One launch = one timestep of every window of the batch; one workgroup = one tile of TILE = NT * PPT children.  A
 // workgroup's timestep is a chain of dependent steps -- reduce the tile partials, place its sorted uniforms among the
-// tiles' cumulative weights, per parent tile: load that tile's scan, search it, gather the parents, propose, weight,
-// write, then the partials of its children -- every link a memory or LDS round trip that nothing inside the workgroup
-// overlaps.  What overlaps them is OTHER workgroups on the same CU: 256 threads and <= 128 VGPRs put four of them
-// there, and a timestep of N = 10^6 particles is one round of 977 workgroups.  The chain itself is kept short:
+// tiles' cumulative weights, per pair of parent tiles: load the tiles' scans, search them, gather the parents, propose,
+// weight, write, then the partials of its children -- every link a memory or LDS round trip that nothing inside the
+// workgroup overlaps.  What overlaps them is OTHER workgroups on the same CU (four at 256 x 4 and <= 128 VGPRs, three at
+// 256 x 8), so the kernel is written to keep the chain short and the registers few:
 //   * three barriers of prologue: every cross-wave exchange (maximum of the tile maxima; totals of the scaled tile
 //     weights, of the spacings, of the statistic sums; wave totals of the children's spacings) shares them;
 //   * the parents' CDF segment is not rebuilt from the log-weights (exp + scan + three barriers per parent tile): the
 //     launch that created the parents stored the tile-local scan of exp(lw - m_b) INSTEAD of the log-weights (8 B per
 //     particle either way), so a parent tile costs one coalesced load, one fused multiply-add per entry, one barrier;
-//     the NEXT parent tile's scan is loaded before the current one is searched;
+//     two parent tiles are handled per pass (a child tile usually descends from one or two);
+//   * the tile bounds of a workgroup's uniforms by G / 64 independent LDS reads + ballots, not log2 G dependent probes;
+//   * the standard normals of a batch of four children are drawn after its parent gathers are issued;
 //   * two barriers of epilogue (grid_dev_epilogue).
 // Traffic per particle-step: scan read 8 B (per parent tile visited: ~2 tiles per child tile on average) + record read
 // + record write + scan write 8 B = the algorithmic 2 (n + 1 + h) w bytes of SURVEY 8(d) plus the second visit's 8 B.
+// Measured steps of this kernel: profiles/r04_ab_grid_tile_classes.txt.
 #pragma once
 #include "pfg_grid_kernel.hpp"
 

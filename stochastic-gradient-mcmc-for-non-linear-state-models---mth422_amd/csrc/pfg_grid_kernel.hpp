@@ -9,7 +9,7 @@
 // Structure: the particle axis is cut into tiles of TILE = 256 * PPT particles (PPT = 4 | 8), one workgroup per tile; one kernel
 // launch per timestep (a dependent launch boundary is ~1.5 us, a software grid barrier 4-7 us, and a boundary also
 // makes the other XCDs' L2 see this step's children).  State lives in a per-window HBM scratch:
-//     lw[2][N]            log-weights, ping-pong by timestep parity
+//     lw[2][N]            log-weights, ping-pong by timestep parity (REPLAY; the device generator writes them for the last step only)
 //     rec[2][N][REC]      particle records {x[NS], stats[H], pad} (array of records: a parent gather is 2-3 16-byte
 //                         vectors from one place), ping-pong
 //     partials[2][..]     per tile: maximum log-weight m_b, W_b = sum exp(lw - m_b), S_b[h] = sum stats_h exp(lw - m_b),
@@ -20,14 +20,16 @@
 //     head[32]            log-likelihood, filter accumulators, tie margin
 //     REPLAY only: cdf[N] (the reference's CDF, bit for bit: pfg_grid_cdf.hpp), coarse[C], walk list
 //
-// DEVICE generator (the throughput path, pfg_grid_step_kernel<.., PFG_RNG_DEVICE>): the resampling uniforms of a timestep
-// are the order statistics of N i.i.d. uniforms (exponential spacings, as pf_big_kernel; multinomial resampling does not
-// care which child gets which uniform), child r takes U_(r).  Children AND parents are then both sorted along the particle
-// axis: the children of tile b descend from a contiguous run of parents, which the workgroup finds with a search over the
-// tiles' cumulative weights and walks tile by tile -- per parent tile it rebuilds the tile's CDF segment in LDS from the
-// log-weights (8 B per parent; no CDF array in memory), searches it, gathers the parent records (monotone addresses:
-// coalesced) and writes its children.  Traffic per particle-step: lw read (>= 8 B) + record read + record write + lw write
-// = 2 (n + 1 + h) w bytes, the algorithmic figure of SURVEY 8(d).
+// DEVICE generator (the throughput path, pfg_grid_step_dev_kernel in pfg_grid_dev_kernel.hpp): the resampling uniforms of a
+// timestep are the order statistics of N i.i.d. uniforms (exponential spacings, as pf_big_kernel; multinomial resampling
+// does not care which child gets which uniform), child r takes U_(r).  Children AND parents are then both sorted along the
+// particle axis: the children of tile b descend from a contiguous run of parents, which the workgroup finds with a search
+// over the tiles' cumulative weights and walks two tiles at a time -- per parent tile it loads the tile-local scan of
+// exp(lw - m_b) that the launch which created the parents stored INSTEAD of their log-weights (cs[2][N], 8 B per particle
+// either way; no CDF array in memory), turns it into the tile's CDF segment in LDS with one fused multiply-add per entry,
+// searches it, gathers the parent records (monotone addresses: coalesced) and writes its children.  Traffic per
+// particle-step: scan read (8 B per parent tile visited, ~2 visits) + record read + record write + scan write: the
+// algorithmic 2 (n + 1 + h) w bytes of SURVEY 8(d) plus the second visit's 8 B (measured 1.20 x, profiles/hbm_traffic.json).
 //
 // REPLAY (the reference's own np.random stream: child i takes u[t][i], z[t][i]): the CDF has to be the reference's --
 // cumsum(p) / cumsum(p)[-1] with the roundings of a SEQUENTIAL fp64 sum, see pfg_grid_cdf.hpp for why and how -- it is

@@ -18,7 +18,7 @@ T = 48
 rs = np.random.RandomState(0)
 y = rs.randn(T) * 1.5
 out = []
-for model, theta, bpp in (("svm", [0.95, 1.414, 1.414], 80), ("garch", [0.0, 2.0, 2.0, 1.8], 112), ("lgssm", [0.9, 1.0, 1.2, 1.0], 96)):
+for model, theta, bpp in ((("svm", [0.95, 1.414, 1.414], 80), ("garch", [0.0, 2.0, 2.0, 1.8], 112), ("lgssm", [0.9, 1.0, 1.2, 1.0], 96)) if os.environ.get("GRID_TIME_DEVICE", "1") == "1" else ()):
     for N in Ns:
         for B in (1, 4):
             if B > 1 and (model != "svm" or N > 1000000):

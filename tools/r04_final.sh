@@ -19,5 +19,7 @@ echo "dropin done"
 timeout -k 10 200 python tools/grid_time.py 100000 1000000 2>&1 | grep -v amdgpu.ids > $OUT/grid_time.txt
 [ -f $CS/libpfgrad_gstamps.so ] && PFGRAD_LIB=$CS/libpfgrad_gstamps.so timeout -k 10 100 python tools/grid_phases.py 100000 1000000 2>&1 | grep -v amdgpu.ids > $OUT/grid_phases.txt
 [ -f $CS/libpfgrad_stamps.so ] && PFGRAD_LIB=$CS/libpfgrad_stamps.so timeout -k 10 100 python tools/phase_profile.py svm 12288 2>&1 | grep -v amdgpu.ids > $OUT/phase_stamps_svm.txt
+# kernel averages of the seed-compatible giant-N call (CDF kernel + step kernel per timestep)
+(cd /tmp && export TMPDIR=/tmp && GRID_TIME_DEVICE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/giant_replay_trace -o trace -- python3 /root/repo/tools/grid_time.py 1000000 > /root/repo/$OUT/giant_replay_trace.out 2> /root/repo/$OUT/giant_replay_trace.err)
 cat $OUT/dropin.txt
 head -c 600 $OUT/bench_default.json

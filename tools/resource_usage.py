@@ -3,7 +3,7 @@
 
 Compiles each instantiation unit with the flags _build.py uses plus -Rpass-analysis=kernel-resource-usage
 and prints one line per kernel: VGPRs, AGPRs, SGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, the
-occupancy the register allocation allows.  `--write` stores the table as profiles/r03_resource_usage.txt
+occupancy the register allocation allows.  `--write` stores the table as profiles/r04_resource_usage.txt
 (LDS is dynamic: the column is what the host asks for at launch, from pfg_variant LDS formulas).
 
     python tools/resource_usage.py [--write] [--units svm_prior_device ...]
@@ -26,6 +26,7 @@ BENCH = {
     "pf_reg_kernel<1, 1, double, 512, 2, 1, false, 0, false, false>": "c3 wg512x2s (GARCH optimal)",
     "pf_reg_kernel<0, 0, double, 1024, 4, 1, false, 0, false, true>": "c4 wg1024x4s_score1 (SVM N=4000)",
     "pf_big_kernel<0, 0, double, 16384>": "c5 big16384 (SVM N=10000)",
+    "pfg_grid_step_dev_kernel<0, 0, double, 256, 8, 2>": "g1 grid2048 (SVM N=10^6)",
 }
 
 
@@ -50,7 +51,7 @@ def unit_records(unit):
             cur[key.strip()] = val.strip()
     names = subprocess.run([CXXFILT] + [r["mangled"] for r in recs], stdout=subprocess.PIPE, text=True).stdout.splitlines()
     for r, n in zip(recs, names):
-        r["name"] = n.replace("void pfg::", "").replace("(pfg_dev_problem const*)", "")
+        r["name"] = n.replace("void pfg::", "").replace("(pfg_dev_problem const*, int)", "").replace("(pfg_dev_problem const*)", "")
         r["unit"] = unit
     return recs
 
@@ -58,9 +59,9 @@ def unit_records(unit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
-    ap.add_argument("--units", nargs="*", default=["{0}_device".format(u) for u in _build._UNITS])
+    ap.add_argument("--units", nargs="*", default=["{0}_{1}".format(u, r) for u in _build._UNITS for r in ("device", "replay")])
     args = ap.parse_args()
-    lines = ["# kernel-resource-usage of the device-generator instantiations (hipcc -Rpass-analysis=kernel-resource-usage,",
+    lines = ["# kernel-resource-usage of every particle-filter instantiation, device-generator and REPLAY units (hipcc -Rpass-analysis=kernel-resource-usage,",
              "# flags of sgmcmc_ssm_amd/_build.py); '*' = an instantiation bench.py times",
              "# {0:<58} {1:>5} {2:>5} {3:>5} {4:>7} {5:>7} {6:>8} {7:>4}  {8}".format(
                  "kernel", "VGPR", "AGPR", "SGPR", "spillV", "spillS", "scratchB", "occ", "unit / bench config")]
@@ -74,7 +75,7 @@ def main():
     out = "\n".join(lines) + "\n"
     sys.stdout.write(out)
     if args.write:
-        with open(os.path.join(ROOT, "profiles", "r03_resource_usage.txt"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "r04_resource_usage.txt"), "w") as f:
             f.write(out)
 
 
