@@ -281,8 +281,8 @@ int pfg_launch_device_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, i
 /* N above the one-workgroup kernels' maximum (16384 < N <= 4194304; the reference has no limit and its bias experiments
  * call pf_gradient_estimate with N = 1000000: gradient_error_fig_scripts/svm_grad_compare.py:68-82): every window of the
  * batch runs as a WHOLE-GPU window -- the particle axis cut into tiles of 1024 (N <= 524288) / 2048 particles, one 256-thread workgroup each, one
- * kernel launch per timestep (T_max + 2 launches on `hip_stream`; REPLAY: 2 T_max + 2, the extra one per timestep builds
- * the reference's CDF -- NumPy's sequential cumsum, bit for bit -- in one workgroup per window).  T_max = the largest T of
+ * kernel launch per timestep (T_max + 2 launches on `hip_stream`; REPLAY: 5 T_max + 2, the extra four per timestep build
+ * the reference's CDF -- NumPy's sequential cumsum, bit for bit -- with the particle axis spread over the GPU).  T_max = the largest T of
  * the batch (the host issues the launches, so it has to know; shorter windows leave theirs at once).  NEMETH / FILTER
  * with the score, sufficient or no statistic.  Every descriptor needs `scratch` of pfg_scratch_bytes(model, dtype, rng, N)
  * bytes (256-byte aligned); windows of one batch must all have N <= 524288 or all N > 524288 (the tile size differs).

@@ -33,7 +33,7 @@
 //
 // REPLAY (the reference's own np.random stream: child i takes u[t][i], z[t][i]): the CDF has to be the reference's --
 // cumsum(p) / cumsum(p)[-1] with the roundings of a SEQUENTIAL fp64 sum, see pfg_grid_cdf.hpp for why and how -- it is
-// materialised in HBM by pfg_grid_cdf_kernel (one workgroup per window), and the step kernel searches it with i.i.d.
+// materialised in HBM by the four pfg_grid_cdf_*_kernel launches (pfg_grid_cdf.hpp), and the step kernel searches it with i.i.d.
 // uniforms: a coarse table (every S-th entry, <= 16384 doubles) in LDS, then log2(S) probes in memory.
 #pragma once
 #include "pfg_big_kernel.hpp"
@@ -44,6 +44,10 @@ constexpr int GRID_MAX_N = 1 << 22;
 constexpr int GRID_MAX_TILES = 2048;           // GRID_MAX_N / 2048
 constexpr int GRID_COARSE_MAX = 16384;
 constexpr int GRID_HEAD_DOUBLES = 32;
+// REPLAY: 8-byte slots the multi-workgroup CDF kernels exchange through: chunk sums [512] | per 4096-block: sum of p, integer
+// total, walk count, integer prefix, reference running sum, its integer position [6][1024] | s_last, walk total [8]
+constexpr int GRID_CDF_CHUNKS = GRID_MAX_N / 8192, GRID_CDF_BLOCKS = GRID_MAX_N / 4096;
+constexpr int GRID_CDFX_SLOTS = GRID_CDF_CHUNKS + 6 * GRID_CDF_BLOCKS + 8;
 // head slots
 constexpr int GH_LL = 0, GH_FILT = 1 /* ..4 */, GH_TIE = 5, GH_WALK = 6, GH_M = 7, GH_W = 8, GH_S = 9 /* ..12 */, GH_ERR = 13;
 
@@ -64,7 +68,7 @@ __host__ __device__ inline int grid_kmax(int N) { return N <= (1 << 20) ? 2 : 8;
 
 struct GridLayout {
     int N, NT, PPT, TILE, G, C, S, PSTRIDE;          // C coarse entries of stride S (REPLAY); PSTRIDE doubles per partial parity
-    size_t lw[2], rec[2], part[2], rng, head, cdf, coarse, walk_i, walk_p, walk_q, walk_s, cs[2], tab, consts, bytes;
+    size_t lw[2], rec[2], part[2], rng, head, cdf, coarse, walk_i, walk_p, walk_q, walk_s, cdfx, cs[2], tab, consts, bytes;
 };
 
 // a ping-pong offset by runtime parity WITHOUT indexing the struct's arrays (dynamic indexing would put the whole
@@ -94,7 +98,7 @@ __host__ __device__ inline GridLayout grid_layout(int N, bool replay) {
     for (int q = 0; q < 2; ++q) { L.part[q] = o; o = grid_align(o + (size_t)L.PSTRIDE * 8); }
     L.rng = o; o = grid_align(o + (size_t)L.G * L.NT * 16);
     L.head = o; o = grid_align(o + GRID_HEAD_DOUBLES * 8);
-    L.cdf = L.coarse = L.walk_i = L.walk_p = L.walk_q = L.walk_s = L.cs[0] = L.cs[1] = L.tab = L.consts = o;
+    L.cdf = L.coarse = L.walk_i = L.walk_p = L.walk_q = L.walk_s = L.cdfx = L.cs[0] = L.cs[1] = L.tab = L.consts = o;
     if (!replay) {
         // device generator: the tile-local inclusive scans of exp(lw - m_b) (what the next launch searches; written
         // instead of the log-weights on the hot path), and the math tables every launch loads into LDS
@@ -109,6 +113,7 @@ __host__ __device__ inline GridLayout grid_layout(int N, bool replay) {
         L.walk_p = o; o = grid_align(o + (size_t)N * 8);
         L.walk_q = o; o = grid_align(o + (size_t)N * 8);
         L.walk_s = o; o = grid_align(o + (size_t)N * 8);
+        L.cdfx = o; o = grid_align(o + (size_t)GRID_CDFX_SLOTS * 8);      // per-chunk / per-block exchange of the CDF kernels (pfg_grid_cdf.hpp)
     }
     L.bytes = o;
     return L;

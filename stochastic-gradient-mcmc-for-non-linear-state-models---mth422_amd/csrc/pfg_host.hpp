@@ -97,7 +97,7 @@ constexpr int kVariantGrid = -7;    // whole-GPU window for N above the one-work
 template <int MODEL, int KERNEL, int RNG>
 int launch_mkr(pfg_ctx *ctx, int dtype, int v, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced);
 
-// the whole-GPU window of one (model, kernel, generator): T_max + 2 (REPLAY: 2 T_max + 2) launches, see pfg_launch.hpp
+// the whole-GPU window of one (model, kernel, generator): T_max + 2 (REPLAY: 5 T_max + 2) launches, see pfg_launch.hpp
 template <int MODEL, int KERNEL, int RNG>
 int launch_grid_mkr(pfg_ctx *ctx, int dtype, int n_max, int t_max, int B, const pfg_dev_problem *dp, hipStream_t st, int phase);
 

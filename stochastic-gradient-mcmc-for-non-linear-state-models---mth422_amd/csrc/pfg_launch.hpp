@@ -183,7 +183,7 @@ int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
 
 
 // ---- whole-GPU window (pfg_grid_kernel.hpp): init, then per timestep [REPLAY: the reference's CDF] + the step kernel,
-// then finish; T_max + 2 (REPLAY: 2 T_max + 2) launches on `st`, no host synchronisation in between.  Every window of the
+// then finish; T_max + 2 (REPLAY: 5 T_max + 2) launches on `st`, no host synchronisation in between.  Every window of the
 // batch must fall into the same tile class (pfg::grid_ppt(N)); windows shorter than t_max leave their launches at once.
 // phase: PFG_GRID_ALL = init, every timestep, finish; PFG_GRID_INIT / PFG_GRID_FINISH alone; t >= 0: timestep t alone
 // (callers that put events or graph nodes between the launches)
@@ -204,8 +204,20 @@ int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_pro
         auto k_step = pfg::pfg_grid_step_kernel<MODEL, KERNEL, REAL, RNG, NT, PPT>;
         const size_t lds_step = pfg::grid_step_lds_bytes<NT, PPT, REAL, RNG>(L.C);
         PFG_ENSURE_LDS(ctx, k_step, lds_step);
+        // the reference's CDF: four launches that spread the particle axis over the GPU (PFGRAD_CDF_SINGLE=1: the
+        // lone-workgroup kernel, A/B and cross-check)
+        const char *single_env = std::getenv("PFGRAD_CDF_SINGLE");
+        const bool cdf_single = single_env && single_env[0] == '1';
+        const unsigned n16 = (unsigned)((n_max + 16383) / 16384), n4 = (unsigned)((n_max + pfg::CDF_BLK - 1) / pfg::CDF_BLK);
         for (int t = t_lo; t < t_hi; ++t) {
-            hipLaunchKernelGGL((pfg::pfg_grid_cdf_kernel<MODEL, REAL>), dim3((unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
+            if (cdf_single) {
+                hipLaunchKernelGGL((pfg::pfg_grid_cdf_kernel<MODEL, REAL>), dim3((unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
+            } else {
+                hipLaunchKernelGGL((pfg::pfg_grid_cdf_sum_kernel<MODEL, REAL>), dim3(n16, (unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
+                hipLaunchKernelGGL((pfg::pfg_grid_cdf_class_kernel<MODEL, REAL>), dim3(n4, (unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
+                hipLaunchKernelGGL((pfg::pfg_grid_cdf_chain_kernel<MODEL, REAL>), dim3((unsigned)B), dim3(pfg::WAVE), 0, st, dp, t);
+                hipLaunchKernelGGL((pfg::pfg_grid_cdf_apply_kernel<MODEL, REAL>), dim3(n4, (unsigned)B), dim3(pfg::CDF_NT), 0, st, dp, t);
+            }
             hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
         }
     } else {

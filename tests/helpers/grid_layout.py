@@ -43,5 +43,6 @@ def grid_layout(model, dtype, N, replay):
         L["walk_p"] = o; o = _al(o + N * 8)
         L["walk_q"] = o; o = _al(o + N * 8)
         L["walk_s"] = o; o = _al(o + N * 8)
+        L["cdfx"] = o; o = _al(o + (512 + 6 * 1024 + 8) * 8)
     L["bytes"] = o
     return L

@@ -147,7 +147,7 @@ def _logweights(kind, N, rs):
 
 @pytest.mark.parametrize("kind", ["normal", "wide", "very_wide", "equal", "one_hot", "decreasing", "increasing", "dyadic"])
 @pytest.mark.parametrize("N", [16385, 65536, 100003, 1000000])
-def test_cdf_kernel_is_numpy_bit_for_bit(ctx, kind, N):
+def test_cdf_kernel_is_numpy_bit_for_bit(ctx, kind, N, monkeypatch):
     """cdf = cumsum(p) / cumsum(p)[-1] with p = exp(lw - max); p /= np.sum(p), as np.random.choice builds it (pf.py:26-30),
     read back from the window's scratch after one REPLAY step with the given log-weights (warm start).  Everything
     downstream of exp is NumPy's arithmetic operation for operation -- the chunked pairwise np.sum, the division, the
@@ -211,6 +211,18 @@ def test_cdf_kernel_is_numpy_bit_for_bit(ctx, kind, N):
     if kind in ("equal", "one_hot", "dyadic"):
         assert frac == 1.0           # exp of these arguments is exact (0, or powers of two) on both sides
     assert nwalk >= 1
+    # the lone-workgroup form of the same kernel (PFGRAD_CDF_SINGLE=1; the default spreads the particle axis over the GPU
+    # in four launches): which steps are walked may differ, the CDF may not -- bitwise, whatever the device's exp returned
+    monkeypatch.setenv("PFGRAD_CDF_SINGLE", "1")
+    scratch.zero_(); anc.zero_()
+    ctx.launch_device_grid(model, "prior", dtype, "replay", N, T, 1, desc.data_ptr(), st)
+    torch.cuda.synchronize(dev)
+    raw1 = scratch.cpu().numpy()
+    cdf1 = raw1[L["cdf"]:L["cdf"] + 8 * N].view(np.float64)
+    assert np.array_equal(cdf1.view(np.uint64), cdf.view(np.uint64))
+    assert np.array_equal(anc.cpu().numpy(), anc_dev)
+    C = L["C"]
+    assert np.array_equal(raw1[L["coarse"]:L["coarse"] + 8 * C], raw[L["coarse"]:L["coarse"] + 8 * C])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
