@@ -608,19 +608,26 @@ __global__ __launch_bounds__(WAVE) void pfg_grid_cdf_chain_kernel(const pfg_dev_
             const int c = __builtin_amdgcn_readlane(cnt, l);
             const unsigned long long qp = readlane_u64(qpre, l);
             const size_t seg = (size_t)(b0 + l) * BLK;
-            for (int e = 0; e < c; ++e) {
-                const double pl = walk_p[seg + e];
-                const unsigned long long ql = qp + walk_q[seg + e];
-                if (nwalk == 0) {
-                    s = pl;                                   // cumsum[0] = p[0]
-                } else {
-                    const int qe = cdf_qexp(cdf_binade(s));
-                    const double before = s + ldexp((double)(ql - qprev), qe);   // exact: multiples of one quantum inside one binade
-                    s = before + pl;                                              // the reference's rounding
+            for (int e0 = 0; e0 < c; e0 += WAVE) {            // 64 entries per coalesced load, chained through readlane
+                const int ne = c - e0 < WAVE ? c - e0 : WAVE;
+                const double pj = lane < ne ? walk_p[seg + e0 + lane] : 0.0;
+                const unsigned long long qj = lane < ne ? walk_q[seg + e0 + lane] : 0ull;
+                double sj = 0.0;
+                for (int e = 0; e < ne; ++e) {
+                    const double pl = readlane_f64(pj, e);
+                    const unsigned long long ql = qp + readlane_u64(qj, e);
+                    if (nwalk == 0) {
+                        s = pl;                               // cumsum[0] = p[0]
+                    } else {
+                        const int qe = cdf_qexp(cdf_binade(s));
+                        const double before = s + ldexp((double)(ql - qprev), qe);   // exact: multiples of one quantum inside one binade
+                        s = before + pl;                                              // the reference's rounding
+                    }
+                    qprev = ql;
+                    ++nwalk;
+                    sj = e == lane ? s : sj;
                 }
-                qprev = ql;
-                ++nwalk;
-                if (lane == 0) walk_s[seg + e] = s;
+                if (lane < ne) walk_s[seg + e0 + lane] = sj;
             }
         }
         if (b < nblk) { X.ref_s[b] = rs; X.ref_q[b] = rq; }
