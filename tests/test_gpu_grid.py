@@ -67,6 +67,7 @@ GIANT = [
     ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 262145, 3, "filter", 1.0),
     ("svm", "prior", [0.9, 1.2, 1.1], 1100003, 3, "poyiadjis_N", 1.0),            # 2048-particle tiles (N > 2^19)
     ("svm", "prior", [0.9, 1.2, 1.1], 50000, 6, "filter", 1.0),
+    ("garch", "prior", [0.0, 2.0, 2.0, 1.8], 4194304, 2, "poyiadjis_N", 1.0),     # the maximum: 2048 tiles, 1024 CDF blocks, 512 np.sum chunks
 ]
 
 
@@ -259,6 +260,7 @@ DEVICE_CASES = [
     ("lgssm", "optimal", [0.9, 1.0, 1.2, 1.0], 100000, 4, "filter", 1.0),
     ("svm", "prior", [0.9, 1.2, 1.1], 300000, 4, "poyiadjis_N", 1.0),
     ("lgssm", "prior", [0.9, 0.7, 1.2, 1.0], 1200000, 3, "nemeth", 0.9),          # 2048-particle tiles (N > 2^19)
+    ("svm", "prior", [0.9, 1.2, 1.1], 4194304, 3, "poyiadjis_N", 1.0),             # the maximum (8 tile partials per thread)
 ]
 
 
