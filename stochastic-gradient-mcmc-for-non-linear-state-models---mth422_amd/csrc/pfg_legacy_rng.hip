@@ -262,9 +262,10 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
     if (nt > 16) nt = 16;
     if (total < 200000) nt = 1;
     const int W = nt - 1;                                       // transform workers
-    int slice_rows = (int)(16384 / (size_t)N);                  // ~8k pairs = 192 KB of attempts per slice
-    if (slice_rows < 1) slice_rows = 1;
-    const size_t cap = ((size_t)slice_rows * N) / 2 + 16;
+    // a slice = ~8k accepted pairs = 192 KB of attempts, whatever the row length (N = 10^6: a row is 61 slices; sliced by
+    // rows it was one 12 MB slice per row in a 96 MB ring)
+    constexpr size_t SLICE_PAIRS = 8192;
+    const size_t cap = SLICE_PAIRS + 156 + 16;
     constexpr int RING = 8;
     std::vector<double> ring_mem;
     try { ring_mem.resize((size_t)RING * 3 * cap); } catch (...) { return PFG_ERR_NOMEM; }
@@ -377,6 +378,7 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
                 if (!(r2 >= 1.0 || r2 == 0.0)) {
                     p1[in_slice] = x1; p2[in_slice] = x2; p3[in_slice] = r2;
                     ++in_slice; ++npairs; --need_pairs;
+                    if (in_slice >= SLICE_PAIRS) close_slice();
                 }
                 continue;
             }
@@ -390,8 +392,9 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
             npairs += got;
             need_pairs -= got;
             mt.pos += 4 * used;
+            if (in_slice >= SLICE_PAIRS) close_slice();
         }
-        if ((row + 1) % slice_rows == 0 || row == T) close_slice();
+        if (row == T) close_slice();
     }
     n_slices.store(j, std::memory_order_release);
     for (auto &th : pool) th.join();
