@@ -267,8 +267,12 @@ extern "C" int pfg_legacy_streams(uint32_t *key, int32_t *pos, int32_t *has_gaus
     constexpr size_t SLICE_PAIRS = 8192;
     const size_t cap = SLICE_PAIRS + 156 + 16;
     constexpr int RING = 8;
-    std::vector<double> ring_mem;
-    try { ring_mem.resize((size_t)RING * 3 * cap); } catch (...) { return PFG_ERR_NOMEM; }
+    // the ring lives as long as the calling thread (1.6 MB; allocating and zero-filling it per call was 40 us of a
+    // 49 k-draw window's 150); the sequential stage owns it for the duration of the call, workers only read their slice
+    static thread_local std::vector<double> ring_mem;
+    if (ring_mem.size() < (size_t)RING * 3 * cap) {
+        try { ring_mem.resize((size_t)RING * 3 * cap); } catch (...) { return PFG_ERR_NOMEM; }
+    }
     // What the workers spin on lives on cache lines of its own: next to the main loop's locals (this stack frame) every
     // poll of a waiting worker would pull the line the sequential stage is writing to (measured on the GPU box's host,
     // two threads: the sequential stage 1.9 -> 5.2 ms with the flags on the stack).
