@@ -462,3 +462,41 @@ def test_giant_f32_state_against_f64(ctx, case, rng, N):
     assert np.linalg.norm(a["mean_stat"] - b["mean_stat"]) <= 5e-2 * scale, (a["mean_stat"], b["mean_stat"])
     assert abs(a["loglik"] - b["loglik"]) <= 5e-3 * max(1.0, abs(a["loglik"])), (a["loglik"], b["loglik"])
     assert not np.array_equal(a["mean_stat"], b["mean_stat"])           # it really is another arithmetic
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# resident windows (what bench.py --config g1 times)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_resident_windows_equal_run_batch_and_graph_replay(ctx):
+    """sgmcmc_ssm_amd.grid.ResidentWindows (descriptors, observations, parameters and scratch resident; T + 2 launches per
+    repetition, the repetition counter on the device) returns BITWISE what pfg_run_batch returns for (seed, stream0 + b,
+    step = repetition) -- the pinned path of test_giant_device_launch_replayed_by_oracle -- and its hipGraph form
+    (launch_graph) bitwise what the eager launches return."""
+    from sgmcmc_ssm_amd.grid import ResidentWindows
+    N, T, B = 30000, 12, 3
+    rs = np.random.RandomState(3)
+    y = rs.normal(size=T) * 1.5
+    th = np.array([[0.95, 1.4, 1.4], [0.9, 1.2, 1.1], [0.8, 1.0, 1.3]])
+    w = rs.uniform(1.0, 3.0, size=6)
+    kw = dict(t1=3, tL=9, weights=w, prior_var=2.0, seed=11, stream0=4)
+    rw = ResidentWindows("svm", y, th, N, **kw)
+    eager = []
+    for rep in range(3):
+        rw.launch()
+        g, ll = rw.results()
+        eager.append((g.copy(), ll.copy()))
+        ref = ctx.run_batch([dict(model="svm", kernel="prior", smoother="nemeth", stat="score", dtype="f64", rng="device", N=N,
+                                  t1=3, tL=9, lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=y, weights=w, theta=th[b],
+                                  seed=11, stream=4 + b, step=rep) for b in range(B)])
+        for b in range(B):
+            assert np.array_equal(g[b], ref[b]["mean_stat"]) and ll[b] == ref[b]["loglik"], (rep, b)
+    assert not np.array_equal(eager[0][0], eager[1][0])                 # a repetition is a fresh draw
+    rg = ResidentWindows("svm", y, th, N, **kw)
+    rg.launch_graph(1)
+    g, ll = rg.results()
+    assert np.array_equal(g, eager[0][0]) and np.array_equal(ll, eager[0][1])
+    rg.launch_graph(2)                                                    # repetitions 1 and 2 in one graph launch
+    g, ll = rg.results()
+    assert np.array_equal(g, eager[2][0]) and np.array_equal(ll, eager[2][1]) and rg.launches == 3
+    rg.launch_graph(1)                                                    # the cached graph again: repetition 3
+    assert rg.launches == 4 and not np.array_equal(rg.results()[0], eager[2][0])
