@@ -33,13 +33,15 @@ int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
     return PFG_OK;
 }
 // ctx->score1: the caller launched with PFG_SMOOTHER_POYIADJIS_N (every descriptor: NEMETH, lambduh = 1, score) -- the
-// 1024 x 4 fp64 device unit has a twin specialised to that (see SCORE1 in pfg_reg_kernel.hpp); every other unit runs
-// its general kernel
+// 1024 x 4 and the one-wave x 2 fp64 device units have a twin specialised to that (see SCORE1 in pfg_reg_kernel.hpp); every
+// other unit runs its general kernel
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
-    if constexpr (NT == 1024 && PPT == 4 && RNG == PFG_RNG_DEVICE && !PP && sizeof(REAL) == 8) {
+    // (measured per unit, whole library built with -DPFG_EXP_PLAIN=1: 1024 x 4 -4.7 %, one wave x 2 -2.8 %, 256 x 4 -0.6 %,
+    // 512 x 2 +2.1 %, large-N kernel 0: profiles/r04_ab_score1_twin.txt)
+    if constexpr (RNG == PFG_RNG_DEVICE && !PP && sizeof(REAL) == 8 && ((NT == 1024 && PPT == 4) || (NT == 64 && PPT == 2))) {
         if (!traced && ctx->score1) {
-            ctx->last_variant = "wg1024x4s_score1";
+            ctx->last_variant = NT == 1024 ? "wg1024x4s_score1" : "wg64x2s_score1";
             return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false, true>(ctx, n_max, B, dp, st);
         }
     }

@@ -113,6 +113,17 @@ def ctx():
     return _capi.default_context(0)
 
 
+def _assert_twin_statistics(production, traced, variant, where=None):
+    """The production launch against the traced kernel the oracle has just replayed, same key.  The trace-free twin is the
+    SAME code with the instrumentation compiled out: bitwise.  A Poyiadjis-score-only twin (`*_score1`) is another
+    specialisation of the unit: same draws, same ancestors, but the compiler fuses multiply-adds of the score differently
+    where the general branch is gone -- equal to a few units in the last place (1e-13), not always bitwise."""
+    if variant.endswith("_score1"):
+        np.testing.assert_allclose(production, traced, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(traced).max())), err_msg=str(where))
+    else:
+        assert np.array_equal(production, traced), where
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "{0}-{1}-{2}-N{4}-T{5}-{7}".format(*c))
 def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
     model, kernel, pf, lam, N, T, window, variant, (NT, PPT, cdf) = case
@@ -140,9 +151,9 @@ def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
     # every step: same terms, other rounding)
     plain = ctx.run_batch([dict(q)])[0]
     # (a window that is the Poyiadjis O(N) score runs the 1024 x 4 unit's specialised twin, PFG_SMOOTHER_POYIADJIS_N)
-    twin = variant + "_score1" if (variant == "wg1024x4s" and smoother == "nemeth" and lam == 1.0) else variant
+    twin = variant + "_score1" if (variant in ("wg1024x4s", "wg64x2s") and smoother == "nemeth" and lam == 1.0) else variant
     assert ctx.last_variant() == twin and ctx.last_traced() == (not variant.startswith("wg"))
-    assert np.array_equal(plain["mean_stat"], o["mean_stat"])
+    _assert_twin_statistics(plain["mean_stat"], o["mean_stat"], twin)
     assert abs(plain["loglik"] - o["loglik"]) <= 1e-12 * abs(o["loglik"])
 
     words, z, z0 = o["rec_u"], o["rec_z"], o["rec_z0"]
@@ -361,7 +372,7 @@ def test_theta_grid_device_kernels_replayed(ctx, monkeypatch, model, tag, theta,
             np.testing.assert_allclose(o["loglik"], ref["loglikelihood_estimate"], rtol=RTOL, atol=ATOL, err_msg=str(where))
         assert np.isfinite(o["loglik"])
         plain = ctx.run_batch([dict(q)])[0]
-        assert np.array_equal(plain["mean_stat"], o["mean_stat"]), where
+        _assert_twin_statistics(plain["mean_stat"], o["mean_stat"], ctx.last_variant(), where)
 
 
 @pytest.mark.parametrize("N,variant,NT", [(10000, "big16384", 16384), (4000, "big4096", 4096), (16384, "big16384", 16384)])

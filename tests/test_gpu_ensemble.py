@@ -411,8 +411,8 @@ def test_device_generator_large_sample():
 
 def test_poyiadjis_n_twin_of_the_1024_thread_unit():
     """PFG_SMOOTHER_POYIADJIS_N launches (what ChainEnsemble issues for lambduh = 1) run the 1024 x 4 fp64 unit's twin with
-    the filter / lambda != 1 / other statistics compiled out: bitwise the numbers of the general kernel (same key, same
-    draws), and a descriptor that is not (NEMETH, lambduh = 1, score) gets NaNs from it, not another estimator's result."""
+    the filter / lambda != 1 / other statistics compiled out: the numbers of the general kernel (same key, same draws; to
+    the last place or two -- the compiler fuses the score's multiply-adds differently where the general branch is gone), and a descriptor that is not (NEMETH, lambduh = 1, score) gets NaNs from it, not another estimator's result."""
     import torch
     from sgmcmc_ssm_amd.ensemble import ChainEnsemble
     from sgmcmc_ssm_amd import _capi
@@ -429,7 +429,7 @@ def test_poyiadjis_n_twin_of_the_1024_thread_unit():
     ens.synchronize()
     assert ens.ctx.last_variant() == "wg1024x4s"
     general = ens.out_dev.cpu().numpy().copy()
-    assert np.isfinite(general[:, :5]).all() and np.array_equal(twin, general)
+    assert np.isfinite(general[:, :5]).all() and np.allclose(twin, general, rtol=1e-13, atol=0.0)      # another specialisation: last-place differences allowed
     # chain 2 asks for lambduh = 0.9, chain 4 for the filter: the twin refuses them, the others are untouched
     d = ens._desc.copy()
     d["lambduh"][2] = 0.9
@@ -439,7 +439,7 @@ def test_poyiadjis_n_twin_of_the_1024_thread_unit():
     ens.ctx.launch_device_smoother(ens.model, ens.kernel, ens.dtype, "device", "poyiadjis_n", ens.N, ens.C, bad.data_ptr(), st)
     ens.synchronize()
     o = ens.out_dev.cpu().numpy()
-    assert np.isnan(o[[2, 4]]).all() and np.array_equal(o[[0, 1, 3, 5]], general[[0, 1, 3, 5]])
+    assert np.isnan(o[[2, 4]]).all() and np.allclose(o[[0, 1, 3, 5]], general[[0, 1, 3, 5]], rtol=1e-13, atol=0.0)
     # the general kernel serves them
     ens.ctx.launch_device(ens.model, ens.kernel, ens.dtype, "device", ens.N, ens.C, bad.data_ptr(), st)
     ens.synchronize()

@@ -48,7 +48,7 @@ def _device_mean(y, p, fm, N, C, kernel="optimal", seed=77):
 def test_device_units_converge_to_the_kalman_gradient(golden_sampler):
     y, p, fm, exact, ll_exact = _setup(golden_sampler)
     bias = {}
-    for N, C, variant in ((100, 16384, "wg64x2s"), (1000, 16384, "wg256x4s"), (4000, 2048, "big4096")):
+    for N, C, variant in ((100, 16384, "wg64x2s_score1"), (1000, 16384, "wg256x4s"), (4000, 2048, "big4096")):
         mean, se, ll, ll_se, v = _device_mean(y, p, fm, N, C)
         assert v == variant
         bias[N] = mean - exact

@@ -81,7 +81,7 @@ def _assert_launch_equals_run_batch(ens, step):
     return variant
 
 
-@pytest.mark.parametrize("model,N,variant", [("svm", 1000, "wg256x4s"), ("garch", 1000, "wg512x2s"), ("lgssm", 100, "wg64x2s")])
+@pytest.mark.parametrize("model,N,variant", [("svm", 1000, "wg256x4s"), ("garch", 1000, "wg512x2s"), ("lgssm", 100, "wg64x2s_score1")])
 def test_full_sequence_launch_is_run_batch_bitwise(model, N, variant):
     from sgmcmc_ssm_amd.ensemble import ChainEnsemble
     y = _series(model, 90)

@@ -21,7 +21,7 @@ from sgmcmc_ssm_amd import _build  # noqa: E402
 CXXFILT = "c++filt"
 # the instantiations bench.py times (config -> demangled template arguments)
 BENCH = {
-    "pf_reg_kernel<2, 1, double, 64, 2, 1, false, 0, false, false>": "c1 wg64x2s (LGSSM optimal)",
+    "pf_reg_kernel<2, 1, double, 64, 2, 1, false, 0, false, true>": "c1 wg64x2s_score1 (LGSSM optimal)",
     "pf_reg_kernel<0, 0, double, 256, 4, 1, false, 0, false, false>": "c2 wg256x4s (SVM, headline)",
     "pf_reg_kernel<1, 1, double, 512, 2, 1, false, 0, false, false>": "c3 wg512x2s (GARCH optimal)",
     "pf_reg_kernel<0, 0, double, 1024, 4, 1, false, 0, false, true>": "c4 wg1024x4s_score1 (SVM N=4000)",
