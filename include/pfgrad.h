@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PFG_VERSION 124          /* 0.1.24 */
+#define PFG_VERSION 125          /* 0.1.25 */
 #define PFG_MAX_STAT 4           /* widest additive statistic (GARCH / LGSSM score) */
 #define PFG_MAX_THETA 4          /* raw parameters per model */
 #define PFG_OUT_DOUBLES 8        /* doubles in one result record (see pfg_dev_problem.out) */
@@ -300,6 +300,15 @@ int pfg_launch_device_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int r
 #define PFG_GRID_PHASE_FINISH (-3)
 int pfg_launch_device_grid_phase(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int phase, int B,
                                  const pfg_dev_problem *dev_probs, void *hip_stream);
+/* Both of the above with the batch's smoother stated (as pfg_launch_device_smoother does for N <= 16384): NEMETH / FILTER
+ * run what the entry points above run; PFG_SMOOTHER_POYIADJIS_N -- every window is (NEMETH, lambduh = 1, score) -- runs a
+ * twin of the device-generator timestep kernel specialised to that estimator (fewer registers: g1 +2.2 %, four windows of
+ * 4 10^5 particles +5.7 %; same numbers to the last place or two).  A window that breaks the statement gets out[0..7] = NaN.
+ * phase = PFG_GRID_PHASE_ALL: the whole window (T_max + 2 launches); otherwise one piece, T_max is ignored.
+ * pfg_run_batch states POYIADJIS_N by itself when every window of a whole-GPU batch qualifies. */
+#define PFG_GRID_PHASE_ALL (-1)
+int pfg_launch_device_grid_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother, int n_max,
+                                    int T_max, int phase, int B, const pfg_dev_problem *dev_probs, void *hip_stream);
 
 /* Buffered-subsequence sampling for resident chains, on the device: for every descriptor b draw
  * a window start as SGMCMCSampler._random_subsequence_and_buffers does (sgmcmc_sampler.py:259-288;

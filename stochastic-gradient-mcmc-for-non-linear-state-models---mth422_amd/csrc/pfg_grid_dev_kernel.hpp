@@ -39,7 +39,11 @@ __host__ __device__ constexpr size_t grid_dev_lds_doubles(int G) {
            (size_t)((NT / WAVE) * (1 + 2 * PPT + PFG_MAX_STAT + 4 + PFG_MAX_STAT) + 8) + (size_t)(TAB_E2_ACC + 2 * TAB_LG);
 }
 
-template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int KMAX>
+// SCORE1 (launches with PFG_SMOOTHER_POYIADJIS_N: every window is NEMETH, lambduh = 1, score): the filter, the lambda != 1
+// shrinkage and the other statistics compiled out -- 167 -> 143 VGPRs (256 x 8), 122 -> 92 (256 x 4), g1 +2.2 %, four
+// windows of 4 10^5 particles +5.7 % (profiles/r04_ab_grid_tile_classes.txt).  A window that is not that estimator is
+// flagged (GH_ERR) and gets NaNs from the finish kernel instead of another estimator's numbers.
+template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int KMAX, bool SCORE1 = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PPT == 4 ? 4 : 3, PPT == 4 ? 4 : 3)))
 void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) {
     constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT, NW = NT / WAVE;
@@ -72,9 +76,15 @@ void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) 
     mth.t.lg = reinterpret_cast<const double2 *>(tabmem + TAB_E2);
     mth.t.sc = reinterpret_cast<const double2 *>(tabmem + TAB_E2 + 2 * TAB_LG);
 
-    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
-    const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : P.lambduh;
+    if constexpr (SCORE1) {
+        if (P.smoother != PFG_SMOOTHER_NEMETH || P.lambduh != 1.0 || P.stat != PFG_STAT_SCORE) {
+            if (b == 0 && tid == 0) head[GH_ERR] = 1.0;
+            return;
+        }
+    }
+    const bool is_filter = !SCORE1 && (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = SCORE1 ? (int)PFG_STAT_SCORE : P.stat;
+    const double lam_d = SCORE1 ? 1.0 : is_filter ? 0.0 : P.lambduh;
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS = is_filter || (lam_d != 1.0);
     const gptr<const double> yv = global_ptr(P.y);

@@ -700,6 +700,9 @@ __global__ __launch_bounds__(NT) void pfg_grid_finish_kernel(const pfg_dev_probl
                 for (int h = 0; h < PFG_MAX_STAT; ++h) P.out[h] = 0.0;
                 for (int h = 0; h < H; ++h) P.out[h] = is_filter ? head[GH_FILT + h] + (T > 0 ? R.S[h] : 0.0) : R.S[h];
                 P.out[4] = ll; P.out[5] = R.W; P.out[6] = R.m; P.out[7] = head[GH_TIE];
+                if (head[GH_ERR] != 0.0) {          // a specialised step kernel refused this window (see SCORE1 in pfg_grid_dev_kernel.hpp)
+                    for (int h = 0; h < PFG_OUT_DOUBLES; ++h) P.out[h] = __builtin_nan("");
+                }
             }
         }
     }

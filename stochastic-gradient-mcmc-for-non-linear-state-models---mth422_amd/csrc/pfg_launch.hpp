@@ -223,10 +223,16 @@ int launch_grid_ppt(pfg_ctx *ctx, int n_max, int t_max, int B, const pfg_dev_pro
             hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
         }
     } else {
-        auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT, KMAX>;
         const size_t lds_step = pfg::grid_dev_lds_doubles<NT, PPT>(L.G) * 8;
-        PFG_ENSURE_LDS(ctx, k_step, lds_step);
-        for (int t = t_lo; t < t_hi; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
+        if (ctx->score1) {                  // PFG_SMOOTHER_POYIADJIS_N: the score-only twin of the step kernel
+            auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT, KMAX, true>;
+            PFG_ENSURE_LDS(ctx, k_step, lds_step);
+            for (int t = t_lo; t < t_hi; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
+        } else {
+            auto k_step = pfg::pfg_grid_step_dev_kernel<MODEL, KERNEL, REAL, NT, PPT, KMAX>;
+            PFG_ENSURE_LDS(ctx, k_step, lds_step);
+            for (int t = t_lo; t < t_hi; ++t) hipLaunchKernelGGL(k_step, grid, blk, lds_step, st, dp, t);
+        }
     }
     if (phase == PFG_GRID_ALL || phase == PFG_GRID_FINISH) hipLaunchKernelGGL(k_fin, grid, blk, lds_fin, st, dp);
     PFG_HIP(ctx, hipGetLastError());

@@ -226,14 +226,19 @@ int dispatch(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max,
 // whole-GPU windows (N above the one-workgroup kernels' maximum, or forced): NEMETH / FILTER with the score,
 // sufficient or no statistic
 int dispatch_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int t_max, int B,
-                  const pfg_dev_problem *dp, hipStream_t st, int phase = -1) {
+                  const pfg_dev_problem *dp, hipStream_t st, int phase = -1, int smoother = PFG_SMOOTHER_NEMETH) {
     int rc = check_combo(ctx, model, kernel, dtype, rng);
     if (rc) return rc;
     if (B <= 0) return PFG_OK;
     if (n_max < 1) return fail(ctx, PFG_ERR_INVALID, "N must be >= 1");
     if (t_max < 0) return fail(ctx, PFG_ERR_INVALID, "T_max must be >= 0");
     if (B > 65535) return fail(ctx, PFG_ERR_INVALID, "at most 65535 whole-GPU windows per launch");
-    ctx->last_variant = pfg::grid_ppt(n_max) == 8 ? "grid2048" : "grid1024";
+    ctx->score1 = smoother == PFG_SMOOTHER_POYIADJIS_N && rng == PFG_RNG_DEVICE;
+    if (ctx->score1) {
+        const char *off = std::getenv("PFGRAD_NO_SCORE1");      // A/B timing: the general kernel for these launches too
+        if (off && off[0] == '1') ctx->score1 = false;
+    }
+    ctx->last_variant = pfg::grid_ppt(n_max) == 8 ? (ctx->score1 ? "grid2048_score1" : "grid2048") : (ctx->score1 ? "grid1024_score1" : "grid1024");
     ctx->last_traced = true;
     if (model == PFG_MODEL_SVM) return launch_grid_mk<PFG_MODEL_SVM, PFG_KERNEL_PRIOR>(ctx, dtype, rng, n_max, t_max, B, dp, st, phase);
     if (model == PFG_MODEL_GARCH) {
@@ -576,6 +581,17 @@ int pfg_launch_device_grid(pfg_ctx *ctx, int model, int kernel, int dtype, int r
     if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid: dev_probs is NULL");
     PFG_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch_grid(ctx, model, kernel, dtype, rng, n_max, T_max, B, dev_probs, (hipStream_t)hip_stream);
+}
+
+int pfg_launch_device_grid_smoother(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int smoother, int n_max, int T_max,
+                                    int phase, int B, const pfg_dev_problem *dev_probs, void *hip_stream) {
+    if (!ctx) return PFG_ERR_INVALID;
+    if (!dev_probs && B > 0) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid_smoother: dev_probs is NULL");
+    if (smoother != PFG_SMOOTHER_NEMETH && smoother != PFG_SMOOTHER_FILTER && smoother != PFG_SMOOTHER_POYIADJIS_N)
+        return fail(ctx, PFG_ERR_UNSUPPORTED, "whole-GPU windows are built for NEMETH / FILTER / POYIADJIS_N");
+    if (phase < PFG_GRID_PHASE_FINISH) return fail(ctx, PFG_ERR_INVALID, "pfg_launch_device_grid_smoother: phase must be PFG_GRID_PHASE_ALL, a timestep >= 0, PFG_GRID_PHASE_INIT or PFG_GRID_PHASE_FINISH");
+    PFG_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch_grid(ctx, model, kernel, dtype, rng, n_max, phase == PFG_GRID_PHASE_ALL ? T_max : 0, B, dev_probs, (hipStream_t)hip_stream, phase, smoother);
 }
 
 int pfg_launch_device_grid_phase(pfg_ctx *ctx, int model, int kernel, int dtype, int rng, int n_max, int phase, int B,
@@ -1043,7 +1059,8 @@ int pfg_run_batch(pfg_ctx *ctx, int B, const pfg_problem *ps, pfg_result *rs) {
                                 hipMemcpyHostToDevice, ctx->stream));
     PFG_HIP(ctx, hipMemsetAsync(ctx->out.ptr, 0, oo * 8, ctx->stream));
     if (variant == kVariantGrid)
-        rc = dispatch_grid(ctx, model, kernel, dtype, rng, n_max, t_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr), ctx->stream);
+        rc = dispatch_grid(ctx, model, kernel, dtype, rng, n_max, t_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr), ctx->stream,
+                           -1, score1 ? PFG_SMOOTHER_POYIADJIS_N : PFG_SMOOTHER_NEMETH);
     else
         rc = dispatch(ctx, model, kernel, dtype, rng, n_max, B, static_cast<const pfg_dev_problem *>(ctx->desc.ptr),
                       ctx->stream, paris ? PFG_SMOOTHER_PARIS : sysres ? PFG_SMOOTHER_NEMETH_SYSTEMATIC

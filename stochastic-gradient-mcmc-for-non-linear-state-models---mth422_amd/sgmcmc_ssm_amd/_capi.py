@@ -133,7 +133,8 @@ EXPORTS = ("pfg_version", "pfg_struct_size", "pfg_create", "pfg_destroy", "pfg_l
            "pfg_ctx_stream", "pfg_launch_device", "pfg_launch_device_smoother", "pfg_scratch_bytes", "pfg_variant_name", "pfg_synchronize",
            "pfg_sgld_update_device", "pfg_sghmc_update_device", "pfg_imq_ksd", "pfg_sample_windows_device",
            "pfg_last_variant", "pfg_legacy_streams", "pfg_host_register", "pfg_host_unregister",
-           "pfg_launch_device_traced", "pfg_last_traced", "pfg_launch_device_grid", "pfg_launch_device_grid_phase")
+           "pfg_launch_device_traced", "pfg_last_traced", "pfg_launch_device_grid", "pfg_launch_device_grid_phase",
+           "pfg_launch_device_grid_smoother")
 
 _lib = None
 
@@ -201,6 +202,8 @@ def load_library():
     lib.pfg_launch_device_grid.restype = C.c_int
     lib.pfg_launch_device_grid_phase.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
     lib.pfg_launch_device_grid_phase.restype = C.c_int
+    lib.pfg_launch_device_grid_smoother.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_void_p]
+    lib.pfg_launch_device_grid_smoother.restype = C.c_int
     lib.pfg_last_traced.argtypes = [C.c_void_p]
     lib.pfg_last_traced.restype = C.c_int
     lib.pfg_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -534,6 +537,16 @@ class Context:
         self._check(self.lib.pfg_launch_device_grid_phase(
             self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], int(n_max), int(phase), int(B),
             C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
+
+    GRID_PHASE_ALL = -1
+
+    def launch_device_grid_smoother(self, model, kernel, dtype, rng, smoother, n_max, T_max, phase, B, dev_probs_ptr, stream_ptr=0):
+        """The whole-GPU window (phase = GRID_PHASE_ALL) or one piece of it with the batch's smoother stated: 'nemeth' /
+        'filter' as launch_device_grid[_phase]; 'poyiadjis_n' (every window NEMETH, lambduh = 1, score) runs the score-only
+        twin of the device-generator timestep kernel."""
+        self._check(self.lib.pfg_launch_device_grid_smoother(
+            self.handle, MODEL[model], KERNEL[kernel], DTYPE[dtype], RNG[rng], SMOOTHER[smoother], int(n_max), int(T_max),
+            int(phase), int(B), C.c_void_p(dev_probs_ptr), C.c_void_p(int(stream_ptr))))
 
     def launch_device_smoother(self, model, kernel, dtype, rng, smoother, n_max, B, dev_probs_ptr, stream_ptr=0):
         self._check(self.lib.pfg_launch_device_smoother(

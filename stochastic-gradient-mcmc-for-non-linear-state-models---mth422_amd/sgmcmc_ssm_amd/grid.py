@@ -25,8 +25,11 @@ class ResidentWindows(object):
         self.kernel = kernel or {"svm": "prior", "garch": "optimal", "lgssm": "optimal"}[model]
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.ctx = _capi.default_context(self.device.index)
+        self._launch_smoother = "nemeth"
         if pf == "poyiadjis_N":
             smoother, lam = "nemeth", 1.0
+            if stat == "score":
+                self._launch_smoother = "poyiadjis_n"   # launch-level statement: the score-only twin of the timestep kernel
         elif pf == "nemeth":
             smoother, lam = "nemeth", 0.95 if lambduh is None else float(lambduh)
         elif pf == "filter":
@@ -75,8 +78,8 @@ class ResidentWindows(object):
     def launch(self, stream=None):
         """One repetition of every window: T + 2 launches on `stream` (default: torch's current stream), asynchronous."""
         st = stream or torch.cuda.current_stream(self.device)
-        self.ctx.launch_device_grid(self.model, self.kernel, self.dtype, "device", self.N, self.T, self.B,
-                                    self.desc_dev.data_ptr(), st.cuda_stream)
+        self.ctx.launch_device_grid_smoother(self.model, self.kernel, self.dtype, "device", self._launch_smoother, self.N, self.T,
+                                             self.ctx.GRID_PHASE_ALL, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
         with torch.cuda.stream(st):
             self.step_ctr += 1          # the next launch draws a fresh repetition (device-side key, no host sync)
         self.launches += 1
@@ -110,16 +113,16 @@ class ResidentWindows(object):
         """The same launches, one `pfg_launch_device_grid_phase` call per timestep with a pair of HIP events around each
         step kernel: returns the list of (start, end) events (read them after a synchronise).  Same numbers as launch()."""
         st = stream or torch.cuda.current_stream(self.device)
-        args = (self.model, self.kernel, self.dtype, "device", self.N)
-        self.ctx.launch_device_grid_phase(*args, self.ctx.GRID_PHASE_INIT, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+        args = (self.model, self.kernel, self.dtype, "device", self._launch_smoother, self.N, self.T)
+        self.ctx.launch_device_grid_smoother(*args, self.ctx.GRID_PHASE_INIT, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
         events = []
         for t in range(self.T):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(st)
-            self.ctx.launch_device_grid_phase(*args, t, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+            self.ctx.launch_device_grid_smoother(*args, t, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
             b.record(st)
             events.append((a, b))
-        self.ctx.launch_device_grid_phase(*args, self.ctx.GRID_PHASE_FINISH, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
+        self.ctx.launch_device_grid_smoother(*args, self.ctx.GRID_PHASE_FINISH, self.B, self.desc_dev.data_ptr(), st.cuda_stream)
         with torch.cuda.stream(st):
             self.step_ctr += 1
         self.launches += 1

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_struct_sizes_and_version():
     lib = _capi.load_library()          # asserts the struct sizes against pfg_struct_size()
-    assert lib.pfg_version() == 124
+    assert lib.pfg_version() == 125
     assert lib.pfg_struct_size(2) == _capi.DEV_PROBLEM_DTYPE.itemsize == 376
     assert lib.pfg_struct_size(99) == -1
     assert lib.pfg_variant_name(0, 0, 0, 1, 1000) == b"wg256x4s"

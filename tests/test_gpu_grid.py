@@ -293,9 +293,16 @@ def test_giant_device_launch_replayed_by_oracle(ctx, case):
     np.testing.assert_allclose(o["all_loglikelihood_estimate"], r["all_loglikelihood_estimate"], rtol=1e-8, atol=1e-8)
     ref = r["statistics"] if pf == "filter" else r["mean_statistic"]
     np.testing.assert_allclose(o["mean_stat"], ref, rtol=1e-7, atol=1e-7)
-    # same key, no recording: bitwise the same result
+    # same key, no recording: bitwise the same result -- or, where the window is the Poyiadjis O(N) score, the score-only
+    # twin of the timestep kernel (PFG_SMOOTHER_POYIADJIS_N: another specialisation, equal to the last place or two)
     o2 = ctx.run_batch([q])[0]
-    assert np.array_equal(o2["mean_stat"], o["mean_stat"]) and o2["loglik"] == o["loglik"]
+    if pf == "poyiadjis_N":
+        assert ctx.last_variant().endswith("_score1")
+        np.testing.assert_allclose(o2["mean_stat"], o["mean_stat"], rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(o["mean_stat"]).max())))
+        assert abs(o2["loglik"] - o["loglik"]) <= 1e-13 * abs(o["loglik"])
+    else:
+        assert not ctx.last_variant().endswith("_score1")
+        assert np.array_equal(o2["mean_stat"], o["mean_stat"]) and o2["loglik"] == o["loglik"]
 
 
 def test_giant_device_sorted_uniforms_are_order_statistics(ctx):
@@ -336,7 +343,7 @@ def test_million_particles_kalman_ground_truth_and_resampling_counts(ctx):
     for s in range(4):
         q["stream"] = s
         outs.append(ctx.run_batch([dict(q)])[0])
-    assert ctx.last_variant() == "grid2048"
+    assert ctx.last_variant() == "grid2048_score1"
     g = np.array([o["mean_stat"] for o in outs])
     ll = np.array([o["loglik"] for o in outs])
     # small-N runs of the one-workgroup kernels on the same data: their mean converges to the same place like 1/N
@@ -455,7 +462,7 @@ def test_giant_f32_state_against_f64(ctx, case, rng, N):
     model, kernel, theta, pf, lam = case
     q = _f32_problem(model, kernel, theta, pf, lam, N, 6, rng, np.random.RandomState(N % 7919))
     b = ctx.run_batch([dict(q)])[0]
-    assert ctx.last_variant() == ("grid2048" if N > (1 << 19) else "grid1024")
+    assert ctx.last_variant() == ("grid2048" if N > (1 << 19) else "grid1024") + ("_score1" if rng == "device" and pf == "poyiadjis_N" else "")
     a = ctx.run_batch([dict(q, dtype="f64")])[0]
     assert np.all(np.isfinite(b["mean_stat"])) and np.isfinite(b["loglik"])
     scale = max(1.0, float(np.linalg.norm(a["mean_stat"])))
@@ -500,3 +507,32 @@ def test_resident_windows_equal_run_batch_and_graph_replay(ctx):
     assert np.array_equal(g, eager[2][0]) and np.array_equal(ll, eager[2][1]) and rg.launches == 3
     rg.launch_graph(1)                                                    # the cached graph again: repetition 3
     assert rg.launches == 4 and not np.array_equal(rg.results()[0], eager[2][0])
+
+
+def test_score_only_twin_refuses_other_estimators(ctx):
+    """PFG_SMOOTHER_POYIADJIS_N launches of the whole-GPU window run the score-only twin of the timestep kernel; a window
+    whose descriptor is not (NEMETH, lambduh = 1, score) must come back as NaNs, the others untouched."""
+    import torch
+    from sgmcmc_ssm_amd.grid import ResidentWindows
+    N, T, B = 30000, 8, 3
+    rs = np.random.RandomState(4)
+    y = rs.normal(size=T)
+    th = np.tile([0.95, 1.4, 1.4], (B, 1))
+    good = ResidentWindows("svm", y, th, N, t1=2, tL=6, prior_var=2.0, seed=5, stream0=1)
+    good.launch()
+    g0, ll0 = good.results()
+    assert good.ctx.last_variant() == "grid1024_score1" and np.isfinite(g0).all()
+    bad = ResidentWindows("svm", y, th, N, t1=2, tL=6, prior_var=2.0, seed=5, stream0=1)
+    bad._desc["lambduh"][1] = 0.9
+    bad.desc_dev.copy_(torch.from_numpy(bad._desc.view(np.uint8).reshape(B, -1)))
+    bad.launch()
+    g1, ll1 = bad.results()
+    assert np.isnan(g1[1]).all() and np.isnan(ll1[1])
+    assert np.array_equal(g1[[0, 2]], g0[[0, 2]]) and np.array_equal(ll1[[0, 2]], ll0[[0, 2]])
+    # stated as NEMETH the same descriptors run the general kernel
+    bad._launch_smoother = "nemeth"
+    bad.step_ctr.zero_()
+    bad.launch()
+    g2, ll2 = bad.results()
+    assert bad.ctx.last_variant() == "grid1024" and np.isfinite(g2).all()
+    np.testing.assert_allclose(g2[[0, 2]], g0[[0, 2]], rtol=1e-13, atol=1e-13)
