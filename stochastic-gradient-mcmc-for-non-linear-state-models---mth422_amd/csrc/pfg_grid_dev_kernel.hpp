@@ -39,12 +39,15 @@ __host__ __device__ constexpr size_t grid_dev_lds_doubles(int G) {
            (size_t)((NT / WAVE) * (1 + 2 * PPT + PFG_MAX_STAT + 4 + PFG_MAX_STAT) + 8) + (size_t)(TAB_E2_ACC + 2 * TAB_LG);
 }
 
+// waves per SIMD: 3 at 256 x 8, 4 at 256 x 4 -- 5 for the SVM's score-only twin (92 VGPRs, 28 KB of LDS: five workgroups per
+// CU; 8 windows of 4 10^5 particles 63.5 -> 62.2 us per step).  GARCH / LGSSM spill 20-34 registers at 5 and lose a third.
+constexpr int grid_dev_occ(int MODEL, int PPT, bool SCORE1) { return PPT == 4 ? (SCORE1 && MODEL == PFG_MODEL_SVM ? 5 : 4) : 3; }
 // SCORE1 (launches with PFG_SMOOTHER_POYIADJIS_N: every window is NEMETH, lambduh = 1, score): the filter, the lambda != 1
 // shrinkage and the other statistics compiled out -- 167 -> 143 VGPRs (256 x 8), 122 -> 92 (256 x 4), g1 +2.2 %, four
 // windows of 4 10^5 particles +5.7 % (profiles/r04_ab_grid_tile_classes.txt).  A window that is not that estimator is
 // flagged (GH_ERR) and gets NaNs from the finish kernel instead of another estimator's numbers.
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int KMAX, bool SCORE1 = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PPT == 4 ? 4 : 3, PPT == 4 ? 4 : 3)))
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(grid_dev_occ(MODEL, PPT, SCORE1), grid_dev_occ(MODEL, PPT, SCORE1))))
 void pfg_grid_step_dev_kernel(const pfg_dev_problem *__restrict__ probs, int t) {
     constexpr int NS = ModelDims<MODEL>::NS, H = ModelDims<MODEL>::H, TILE = NT * PPT, NW = NT / WAVE;
     constexpr int REC = mem_rec_len<MODEL, REAL>();
