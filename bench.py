@@ -456,7 +456,10 @@ def replay_arithmetic_leg(w, dev_index, C=None, reps=3):
     st = torch.cuda.current_stream(dev)
 
     def launch():
-        ens.ctx.launch_device(ens.model, ens.kernel, ens.dtype, "replay", N, C, ens.desc_dev.data_ptr(), st.cuda_stream)
+        # every window is the Poyiadjis O(N) score: the launch says so (PFG_SMOOTHER_POYIADJIS_N), as pfg_run_batch does for
+        # such a batch -- units with a score-only twin run it (bitwise the general kernel's numbers in the REPLAY units)
+        ens.ctx.launch_device_smoother(ens.model, ens.kernel, ens.dtype, "replay", "poyiadjis_n", N, C, ens.desc_dev.data_ptr(),
+                                       st.cuda_stream)
 
     launch()
     torch.cuda.synchronize(dev)

@@ -68,8 +68,9 @@ enum pfg_smoother { PFG_SMOOTHER_NEMETH = 0, PFG_SMOOTHER_FILTER = 1, PFG_SMOOTH
                      * every descriptor of the batch is the Poyiadjis O(N) score -- smoother = NEMETH, lambduh = 1.0,
                      * stat = SCORE (what pf = 'poyiadjis_N' means, pf.py:139-180).  Same kernels and the same numbers
                      * as NEMETH; the 1024 x 4 (1024 < N <= 4096) and the one-wave x 2 (N <= 128, batches) fp64
-                     * device-generator units run a twin with the filter, the lambda != 1 shrinkage and the other
-                     * statistics compiled out (BASELINE config 4: -3.9 %, config 1: -2.8 %).
+                     * device-generator units, and the 256 x 4 / one-wave x 2 REPLAY units of SVM and LGSSM, run a twin
+                     * with the filter, the lambda != 1 shrinkage and the other statistics compiled out (BASELINE config
+                     * 4: -3.9 %, config 1: -3.8 %; seed-compatible arithmetic -4.6 % / -6.2 %, bitwise the same numbers).
                      * A descriptor that breaks the statement gets out[0..7] = NaN from that twin.  pfg_run_batch
                      * chooses it by itself when every window of the batch qualifies. */
                     PFG_SMOOTHER_POYIADJIS_N = 5 };

@@ -37,11 +37,15 @@ int launch_one_t(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipS
 // other unit runs its general kernel
 template <int MODEL, int KERNEL, typename REAL, int NT, int PPT, int RNG, bool PP>
 int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool traced) {
-    // (measured per unit, whole library built with -DPFG_EXP_PLAIN=1: 1024 x 4 -4.7 %, one wave x 2 -2.8 %, 256 x 4 -0.6 %,
-    // 512 x 2 +2.1 %, large-N kernel 0: profiles/r04_ab_score1_twin.txt)
-    if constexpr (RNG == PFG_RNG_DEVICE && !PP && sizeof(REAL) == 8 && ((NT == 1024 && PPT == 4) || (NT == 64 && PPT == 2))) {
+    // (measured per unit, whole library built with -DPFG_EXP_PLAIN=1 -- device generator: 1024 x 4 -4.7 %, one wave x 2
+    // -2.8 %, 256 x 4 -0.6 %, 512 x 2 +2.1 %, large-N kernel 0; REPLAY arithmetic legs: SVM 256 x 4 -5.8 %, LGSSM one wave
+    // -6.5 %, GARCH 256 x 4 +8 %: profiles/r04_ab_score1_twin.txt)
+    constexpr bool dev_unit = RNG == PFG_RNG_DEVICE && !PP && ((NT == 1024 && PPT == 4) || (NT == 64 && PPT == 2));
+    constexpr bool rep_unit = RNG == PFG_RNG_REPLAY && MODEL != PFG_MODEL_GARCH && ((NT == 256 && PPT == 4) || (NT == 64 && PPT == 2));
+    if constexpr (sizeof(REAL) == 8 && (dev_unit || rep_unit)) {
         if (!traced && ctx->score1) {
-            ctx->last_variant = NT == 1024 ? "wg1024x4s_score1" : "wg64x2s_score1";
+            ctx->last_variant = NT == 1024 ? "wg1024x4s_score1" : NT == 256 ? (PP ? "wg256x4_score1" : "wg256x4s_score1")
+                                                                 : (PP ? "wg64x2_score1" : "wg64x2s_score1");
             return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false, true>(ctx, n_max, B, dp, st);
         }
     }

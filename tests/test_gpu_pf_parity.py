@@ -504,3 +504,37 @@ def test_replay_production_twin_equals_traced_twin(ctx, monkeypatch, model, kern
         assert np.array_equal(x["mean_stat"], y_["mean_stat"]) and np.array_equal(x["x_t"], y_["x_t"])
         assert np.array_equal(x["log_weights"], y_["log_weights"])
         assert abs(x["loglik"] - y_["loglik"]) <= 1e-12 * abs(y_["loglik"])
+
+
+@pytest.mark.parametrize("model,kernel,N,variant", [("svm", "prior", 1000, "wg256x4s"), ("svm", "prior", 1000, "wg256x4"),
+                                                    ("lgssm", "optimal", 100, "wg64x2"), ("lgssm", "prior", 777, "wg256x4s")])
+def test_replay_score_only_twin_is_bitwise_the_general_kernel(ctx, monkeypatch, model, kernel, N, variant):
+    """A batch whose windows are all the Poyiadjis O(N) score (NEMETH, lambduh = 1, score) runs the seed-compatible units'
+    twin with the filter / lambda != 1 / other statistics compiled out (PFG_SMOOTHER_POYIADJIS_N, chosen by pfg_run_batch).
+    The REPLAY units are built without floating-point contraction, so the twin is the general kernel's arithmetic operation
+    for operation: BITWISE the same result record and final particles.  PFGRAD_NO_SCORE1=1 launches the general kernel."""
+    rs = np.random.RandomState(N)
+    theta = {"svm": [0.95, 1.2, 1.3], "lgssm": [0.9, 1.0, 1.2, 1.0]}[model]
+    probs = []
+    for b in range(4):
+        T = 30 + b
+        z0, u, z = po.draw_streams(rs, N, T)
+        probs.append(dict(model=model, kernel=kernel, smoother="nemeth", stat="score", dtype="f64", rng="replay", N=N, t1=2, tL=T - 3,
+                          lambduh=1.0, prior_mean=0.0, prior_var=2.0, y=rs.normal(size=T), weights=rs.uniform(0.5, 3.0, size=T - 5),
+                          theta=theta, z0=z0, u=u, z=z))
+    monkeypatch.setenv("PFGRAD_VARIANT", variant)
+    twin = ctx.run_batch([dict(q) for q in probs], want_final=True)
+    assert ctx.last_variant() == variant + "_score1"
+    monkeypatch.setenv("PFGRAD_NO_SCORE1", "1")
+    general = ctx.run_batch([dict(q) for q in probs], want_final=True)
+    assert ctx.last_variant() == variant
+    for a, g in zip(twin, general):
+        assert np.array_equal(a["mean_stat"], g["mean_stat"]) and a["loglik"] == g["loglik"]
+        assert np.array_equal(a["x_t"], g["x_t"]) and np.array_equal(a["log_weights"], g["log_weights"]) and np.array_equal(a["statistics"], g["statistics"])
+    # one window with lambduh = 0.9 in the batch: pfg_run_batch does not state POYIADJIS_N, the general kernel runs
+    monkeypatch.delenv("PFGRAD_NO_SCORE1")
+    mixed = [dict(q) for q in probs]
+    mixed[1]["lambduh"] = 0.9
+    out = ctx.run_batch(mixed, want_final=True)
+    assert ctx.last_variant() == variant
+    assert np.array_equal(out[0]["mean_stat"], general[0]["mean_stat"]) and not np.array_equal(out[1]["mean_stat"], general[1]["mean_stat"])
