@@ -40,12 +40,14 @@ int launch_one(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStr
     // (measured per unit, whole library built with -DPFG_EXP_PLAIN=1 -- device generator: 1024 x 4 -4.7 %, one wave x 2
     // -2.8 %, 256 x 4 -0.6 %, 512 x 2 +2.1 %, large-N kernel 0; REPLAY arithmetic legs: SVM 256 x 4 -5.8 %, LGSSM one wave
     // -6.5 %, GARCH 256 x 4 +8 %: profiles/r04_ab_score1_twin.txt)
+    // ... and the 1024 x 1 latency variant (one window alone, SVM T = N = 1000): device 1.957 -> 1.814 ms, REPLAY 2.768 -> 2.623)
+    constexpr bool lat_unit = MODEL != PFG_MODEL_GARCH && NT == 1024 && PPT == 1 && PP;
     constexpr bool dev_unit = RNG == PFG_RNG_DEVICE && !PP && ((NT == 1024 && PPT == 4) || (NT == 64 && PPT == 2));
     constexpr bool rep_unit = RNG == PFG_RNG_REPLAY && MODEL != PFG_MODEL_GARCH && ((NT == 256 && PPT == 4) || (NT == 64 && PPT == 2));
-    if constexpr (sizeof(REAL) == 8 && (dev_unit || rep_unit)) {
+    if constexpr (sizeof(REAL) == 8 && (dev_unit || rep_unit || lat_unit)) {
         if (!traced && ctx->score1) {
-            ctx->last_variant = NT == 1024 ? "wg1024x4s_score1" : NT == 256 ? (PP ? "wg256x4_score1" : "wg256x4s_score1")
-                                                                 : (PP ? "wg64x2_score1" : "wg64x2s_score1");
+            ctx->last_variant = NT == 1024 ? (PPT == 4 ? "wg1024x4s_score1" : "wg1024x1_score1")
+                                : NT == 256 ? (PP ? "wg256x4_score1" : "wg256x4s_score1") : (PP ? "wg64x2_score1" : "wg64x2s_score1");
             return launch_one_t<MODEL, KERNEL, REAL, NT, PPT, RNG, PP, false, true>(ctx, n_max, B, dp, st);
         }
     }

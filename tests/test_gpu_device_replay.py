@@ -151,7 +151,10 @@ def test_device_kernel_replayed_by_oracle(ctx, monkeypatch, case):
     # every step: same terms, other rounding)
     plain = ctx.run_batch([dict(q)])[0]
     # (a window that is the Poyiadjis O(N) score runs the 1024 x 4 unit's specialised twin, PFG_SMOOTHER_POYIADJIS_N)
-    twin = variant + "_score1" if (variant in ("wg1024x4s", "wg64x2s") and smoother == "nemeth" and lam == 1.0) else variant
+    score = smoother == "nemeth" and lam == 1.0
+    twin = variant
+    if score and (variant in ("wg1024x4s", "wg64x2s") or (variant == "wg1024x1" and model != "garch")):
+        twin = variant + "_score1"
     assert ctx.last_variant() == twin and ctx.last_traced() == (not variant.startswith("wg"))
     _assert_twin_statistics(plain["mean_stat"], o["mean_stat"], twin)
     assert abs(plain["loglik"] - o["loglik"]) <= 1e-12 * abs(o["loglik"])
