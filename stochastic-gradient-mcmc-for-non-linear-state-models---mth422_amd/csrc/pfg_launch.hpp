@@ -176,7 +176,12 @@ int launch_systematic(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp,
 template <int MODEL, int KERNEL, typename REAL, int RNG>
 int launch_mem(pfg_ctx *ctx, int n_max, int B, const pfg_dev_problem *dp, hipStream_t st, bool lw4 = false) {
     size_t lds = pfg::mem_kernel_lds_bytes<REAL, RNG>(n_max);
-    if (lw4 && n_max <= 4096) {
+    if (lw4 && n_max <= 4096 && ctx->score1 && sizeof(REAL) == 8 && MODEL != PFG_MODEL_GARCH) {      // (GARCH: unmeasured here, +8 % in the LDS-resident REPLAY unit)
+        auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, false, true, true>;      // the score-only twin (see SCORE1)
+        PFG_ENSURE_LDS(ctx, kern, lds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);
+        ctx->last_variant = "mem1024_score1";
+    } else if (lw4 && n_max <= 4096) {
         auto kern = pfg::pf_mem_kernel<MODEL, KERNEL, REAL, RNG, false, true>;
         PFG_ENSURE_LDS(ctx, kern, lds);
         hipLaunchKernelGGL(kern, dim3(B), dim3(pfg::MEM_NT), lds, st, dp);

@@ -79,9 +79,14 @@ __host__ __device__ inline size_t mem_kernel_lds_bytes(int N) {
 // LW4 (round 4; N <= 4096, plain statistics, not PaRIS): a thread's (<= 4) log-weights never leave its registers -- it is
 // their only reader and writer --, which takes the global-memory round trip out of the maximum and the weight phases
 // of every timestep (BASELINE config 4 through the seed-compatible path).
-template <int MODEL, int KERNEL, typename REAL, int RNG, bool PARIS = false, bool LW4 = false>
+// SCORE1 (PFG_SMOOTHER_POYIADJIS_N launches of the N <= 4096 variant): the Poyiadjis O(N) score only -- the filter, the
+// lambda != 1 shrinkage and the other statistics compiled out.  BASELINE config 4 through the seed-compatible path:
+// 37.9 -> 32.1 ms per 402 windows (-15 %; the N = 10^4 kernel gains nothing: profiles/r04_ab_score1_twin.txt).  REPLAY
+// units are built without contraction: bitwise the general kernel's numbers.  A window that is not that estimator gets NaNs.
+template <int MODEL, int KERNEL, typename REAL, int RNG, bool PARIS = false, bool LW4 = false, bool SCORE1 = false>
 __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *__restrict__ probs) {
     static_assert(!(PARIS && LW4), "LW4 is a variant of the plain kernel");
+    static_assert(!SCORE1 || LW4, "the score-only twin exists for the N <= 4096 variant");
     constexpr int NS = ModelDims<MODEL>::NS;
     constexpr int H = ModelDims<MODEL>::H;
     constexpr int NT = MEM_NT, NW = MEM_NW;
@@ -101,9 +106,15 @@ __global__ __launch_bounds__(MEM_NT) void pf_mem_kernel(const pfg_dev_problem *_
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int nchunk = (N + NT - 1) / NT;
     const int np2 = mem_np2(N);
-    const bool is_filter = (P.smoother == PFG_SMOOTHER_FILTER);
-    const int stat = P.stat;
-    const double lam_d = is_filter ? 0.0 : (PARIS ? 1.0 : P.lambduh);
+    if constexpr (SCORE1) {
+        if (P.smoother != PFG_SMOOTHER_NEMETH || P.lambduh != 1.0 || P.stat != PFG_STAT_SCORE) {
+            if (threadIdx.x < PFG_OUT_DOUBLES && P.out) P.out[threadIdx.x] = __builtin_nan("");
+            return;
+        }
+    }
+    const bool is_filter = !SCORE1 && (P.smoother == PFG_SMOOTHER_FILTER);
+    const int stat = SCORE1 ? (int)PFG_STAT_SCORE : P.stat;
+    const double lam_d = SCORE1 ? 1.0 : is_filter ? 0.0 : (PARIS ? 1.0 : P.lambduh);
     const REAL lam = (REAL)lam_d, oml = (REAL)(1.0 - lam_d);
     const bool needS_every = is_filter || (lam_d != 1.0);
     const double *__restrict__ const yv = P.y;

@@ -508,7 +508,8 @@ def test_replay_production_twin_equals_traced_twin(ctx, monkeypatch, model, kern
 
 @pytest.mark.parametrize("model,kernel,N,variant", [("svm", "prior", 1000, "wg256x4s"), ("svm", "prior", 1000, "wg256x4"),
                                                     ("lgssm", "optimal", 100, "wg64x2"), ("lgssm", "prior", 777, "wg256x4s"),
-                                                    ("svm", "prior", 1000, "wg1024x1")])
+                                                    ("svm", "prior", 1000, "wg1024x1"), ("svm", "prior", 4000, "mem1024"),
+                                                    ("lgssm", "optimal", 2500, "mem1024")])
 def test_replay_score_only_twin_is_bitwise_the_general_kernel(ctx, monkeypatch, model, kernel, N, variant):
     """A batch whose windows are all the Poyiadjis O(N) score (NEMETH, lambduh = 1, score) runs the seed-compatible units'
     twin with the filter / lambda != 1 / other statistics compiled out (PFG_SMOOTHER_POYIADJIS_N, chosen by pfg_run_batch).
