@@ -1,6 +1,6 @@
 #!/bin/bash
 # ThreadSanitizer + AddressSanitizer runs of the host-only threaded code of libpfgrad (the legacy-stream generator,
-# csrc/pfg_legacy_rng.hip), CPU builds with g++.  Logs -> profiles/r03_tsan_legacy_rng.txt / r03_asan_legacy_rng.txt.
+# csrc/pfg_legacy_rng.hip), CPU builds with g++.  Logs -> profiles/r04_tsan_legacy_rng.txt / r04_asan_legacy_rng.txt.
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CS=$ROOT/stochastic-gradient-mcmc-for-non-linear-state-models---mth422_amd/csrc
@@ -9,7 +9,7 @@ for san in thread address; do
   exe=/tmp/pfg_${san}_legacy
   g++ -std=c++17 -O1 -g -fsanitize=$san -fno-omit-frame-pointer -ffp-contract=off -mavx2 -pthread -I $ROOT/include \
       -x c++ $CS/pfg_legacy_rng.hip $ROOT/tools/sanitize/tsan_legacy_rng.cpp -o $exe
-  log=$OUT/r03_$( [ $san == thread ] && echo tsan || echo asan )_legacy_rng.txt
+  log=$OUT/r04_$( [ $san == thread ] && echo tsan || echo asan )_legacy_rng.txt
   { echo "# g++ -fsanitize=$san build of csrc/pfg_legacy_rng.hip + tools/sanitize/tsan_legacy_rng.cpp ($(date -u +%F))";
     echo "# command: $exe ; exit status and sanitizer reports below (none = clean)";
     set +e; $exe 2>&1; echo "exit status: $?"; set -e; } > $log
